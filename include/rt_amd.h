@@ -1,0 +1,154 @@
+/* rt_amd.h -- C ABI of the MI355X render path.
+ *
+ * The reference (a Rust CPU ray tracer) has no FFI of its own.  Its render seam is the
+ * method pair
+ *     RayTracer::new(config: Config) -> RayTracer          src/raytracer/raytracer.rs:29
+ *     RayTracer::render(&self) -> Result<Image, String>    src/raytracer/raytracer.rs:40
+ * and these entry points are what a patched `new`/`render` would bind through
+ * `extern "C"` (one `rt_upload_scene` in `new`, one `rt_render` in `render`).
+ *
+ * Conventions
+ *   - every struct is plain data, little endian, float = IEEE binary32;
+ *   - arrays passed in are owned by the caller and only borrowed for the duration of the call;
+ *   - the library owns device memory between rt_upload_scene and rt_shutdown;
+ *   - every function returns 0 on success; on failure it returns non-zero and
+ *     rt_last_error() describes it (the Err(String) of the reference); nothing aborts;
+ *   - calls are blocking and come from one thread at a time, like the reference's render();
+ *   - one process drives one GPU (rt_init(device)); multi-GPU jobs run one process per GPU
+ *     and shard the frame by interleaved row tiles (rt_render_tiles).
+ *   - pixels are 0xFFRRGGBB, row-major, first row on top (src/raytracer/raytracer.rs:85-91,
+ *     src/imgcomparator/mod.rs:14-25).
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-frame constants: the values RayTracer::render computes once before its pixel loop
+ * (src/raytracer/raytracer.rs:46-55) plus the Config fields the loop reads. */
+typedef struct rt_frame {
+    float pos[3];        /* camera.position                                   raytracer.rs:68  */
+    float cv[3];         /* camera_vector = normalize(camera.direction())     raytracer.rs:46  */
+    float right[3];      /* normal_to_plane = normalize(cv x up)              raytracer.rs:47  */
+    float up[3];         /* v = normalize(right x cv)                         raytracer.rs:48  */
+    float pixel_w;       /* pixel_width                                       raytracer.rs:52  */
+    float pixel_h;       /* pixel_height = tan(fovrad / 2)                    raytracer.rs:51  */
+    float half_w;        /* img_width_by_2                                    raytracer.rs:54  */
+    float half_h;        /* img_height_by_2                                   raytracer.rs:55  */
+    uint32_t width;      /* config.width                                                       */
+    uint32_t height;     /* config.height                                                      */
+    uint32_t maxdepth;   /* config.maxdepth                                   raytracer.rs:187 */
+    float ambient[3];    /* config.ambient                                    raytracer.rs:181 */
+} rt_frame;
+
+/* Fills an rt_frame from the camera of the scene file exactly as raytracer.rs:46-55 and
+ * camera.rs:11-13 do (strict binary32, tanf on the host). */
+int rt_frame_from_camera(const float position[3], const float look_at[3], const float up[3], float fov_degrees,
+                         uint32_t width, uint32_t height, uint32_t maxdepth, const float ambient[3],
+                         rt_frame* out);
+
+/* Flattened scene: Config.scene_objects and Config.lights (config_builder.rs:22-23,
+ * shape.rs:5-32, light.rs:3-6) as structure-of-arrays.  Shapes keep file order inside each
+ * kind; `*_order` gives each shape's position in the file (used only to break exact
+ * distance ties the way a file-order scan would; may be NULL = kinds concatenated
+ * triangles, spheres, planes). */
+typedef struct rt_scene {
+    const float* tri_v0;        /* 3 * ntri : Triangle.v0                                  */
+    const float* tri_v1;        /* 3 * ntri : Triangle.v1                                  */
+    const float* tri_v2;        /* 3 * ntri : Triangle.v2                                  */
+    const float* sph_center;    /* 3 * nsph : Sphere.center                                */
+    const float* sph_radius;    /*     nsph : Sphere.radius                                */
+    const float* pl_point;      /* 3 * npl  : Plane.point                                  */
+    const float* pl_normal;     /* 3 * npl  : Plane.normal, already normalised by the parser (config_builder.rs:445-450) */
+    const float* tri_mat;       /* 7 * ntri : diffuse rgb, specular rgb, shininess         */
+    const float* sph_mat;       /* 7 * nsph                                                */
+    const float* pl_mat;        /* 7 * npl                                                 */
+    const uint32_t* tri_order;  /* ntri or NULL */
+    const uint32_t* sph_order;  /* nsph or NULL */
+    const uint32_t* pl_order;   /* npl  or NULL */
+    uint32_t ntri, nsph, npl;
+    const float* lights;        /* 7 * nlights : kind (0 = point, 1 = directional), vec3 (position, or unit
+                                   direction towards the light, normalised by the parser), colour rgb   */
+    uint32_t nlights;
+} rt_scene;
+
+typedef struct rt_stats {
+    uint64_t primary;        /* primary rays   = pixels rendered by this call               */
+    uint64_t shadow;         /* shadow rays    = one per (hit, light)     raytracer.rs:126-141 */
+    uint64_t secondary;      /* reflection rays actually spawned          raytracer.rs:192  */
+    uint64_t nodes_visited;  /* bounding boxes tested (32 bytes each)                       */
+    uint64_t prims_tested;   /* exact shape tests (48 bytes each)                           */
+    double kernel_ms;        /* render kernel(s), HIP events on the library's stream        */
+    double total_ms;         /* whole call, host clock                                      */
+} rt_stats;
+
+/* rt_build information about the tree the library built for the resident scene. */
+typedef struct rt_bvh_info {
+    uint32_t node_pairs;     /* 64-byte records: two 32-byte child boxes each               */
+    uint32_t leaves;
+    uint32_t max_depth;
+    uint32_t max_leaf;       /* largest number of shapes in one leaf                        */
+    uint32_t bvh_prims;      /* shapes inside the tree                                      */
+    uint32_t list_prims;     /* shapes always tested (planes; everything in tiny scenes)    */
+    double build_ms;
+    double sah_cost;
+} rt_bvh_info;
+
+/* Binds the library to HIP device `device` and creates its stream.  Replaces nothing in the
+ * reference (it has no device); called once before RayTracer::new. */
+int rt_init(int device);
+
+/* RayTracer::new (raytracer.rs:29-38): builds the bounding volume hierarchy on the host
+ * (the reference calls Bvh::build_par at raytracer.rs:32), lays the scene out for the GPU
+ * and uploads it.  The scene stays resident until the next upload or rt_shutdown. */
+int rt_upload_scene(const rt_scene* scene);
+
+int rt_get_bvh_info(rt_bvh_info* out);
+
+/* The resident scene as one contiguous device blob (for replicating it to other GPUs with
+ * a broadcast) and the inverse: adopt a blob that was received into device memory owned by
+ * the caller, which must stay valid until the next upload/adopt/shutdown. */
+int rt_scene_blob(void** device_ptr, size_t* bytes);
+int rt_adopt_scene_blob(void* device_ptr, size_t bytes);
+
+/* RayTracer::render (raytracer.rs:40-79): renders the whole frame into host memory,
+ * out_pixels[width * height].  `stats` may be NULL; when `count_work` is non-zero the
+ * instrumented kernel also fills nodes_visited / prims_tested / shadow / secondary
+ * (slower; never used for timing). */
+int rt_render(const rt_frame* frame, uint32_t* out_pixels, rt_stats* stats, int count_work);
+
+/* The same loop restricted to the row tiles owned by one shard: tile t (rows
+ * [t*tile_rows, (t+1)*tile_rows)) belongs to shard t % nshards.  Rows of the owned tiles are
+ * written compactly, in increasing order, to the DEVICE buffer d_out (rt_shard_rows() rows of
+ * `width` pixels).  Rows of the frame are independent in the reference too
+ * (par_chunks_mut, raytracer.rs:57-59).  Asynchronous on rt_stream() unless stats != NULL. */
+int rt_render_tiles(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32_t tile_rows,
+                    uint32_t* d_out, rt_stats* stats, int count_work);
+uint32_t rt_shard_rows(uint32_t height, uint32_t shard, uint32_t nshards, uint32_t tile_rows);
+
+/* Inverse of the sharding on the gathering GPU: d_gathered holds nshards compact buffers of
+ * `rows_per_shard_stride` rows each (shard s at offset s * stride * width pixels); writes the
+ * assembled frame to d_frame[width * height]. */
+int rt_assemble_tiles(const uint32_t* d_gathered, uint32_t rows_per_shard_stride, uint32_t nshards,
+                      uint32_t tile_rows, uint32_t width, uint32_t height, uint32_t* d_frame);
+
+/* The HIP stream (hipStream_t) the library launches on, for callers that order their own
+ * device work or events against it. */
+void* rt_stream(void);
+int rt_synchronize(void);
+
+/* Err(String) of the last failing call on this thread. */
+const char* rt_last_error(void);
+
+/* Frees the resident scene, work buffers and the stream. */
+void rt_shutdown(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

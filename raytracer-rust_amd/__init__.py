@@ -1,0 +1,384 @@
+"""MI355X render path of the ray tracer, host side in Python.
+
+The names mirror the reference's Rust API so that callers and tests read the same way:
+
+    ParsedConfigState().load_config_file(path) -> Config     config_builder.rs:119-150
+    RayTracer(config)  (RayTracer::new)                      raytracer.rs:29-38
+    RayTracer.render() -> Image                              raytracer.rs:40-79
+    RayTracer.get_output_path()                              raytracer.rs:81-83
+    Image.compare(a, b) -> (count, diff_image)               imgcomparator/mod.rs:54-89
+    file_to_image / save_image / extract_rgb                 imgcomparator/mod.rs:100-165
+
+Everything that computes goes through the C ABI of include/rt_amd.h / include/rt_host.h in
+librt_amd.so (hand-written gfx950 kernels).  There is no CPU or PyTorch fallback: if the
+library is missing or no GPU is usable the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+TILE_ROWS = 8   # rows per interleaved tile when a frame is sharded over GPUs
+
+
+class RtError(RuntimeError):
+    """Err(String) of the reference: the message of the failing call."""
+
+
+class rt_frame(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("cv", C.c_float * 3), ("right", C.c_float * 3), ("up", C.c_float * 3),
+                ("pixel_w", C.c_float), ("pixel_h", C.c_float), ("half_w", C.c_float), ("half_h", C.c_float),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("maxdepth", C.c_uint32), ("ambient", C.c_float * 3)]
+
+
+_FP = C.POINTER(C.c_float)
+_UP = C.POINTER(C.c_uint32)
+
+
+class rt_scene(C.Structure):
+    _fields_ = [("tri_v0", _FP), ("tri_v1", _FP), ("tri_v2", _FP), ("sph_center", _FP), ("sph_radius", _FP),
+                ("pl_point", _FP), ("pl_normal", _FP), ("tri_mat", _FP), ("sph_mat", _FP), ("pl_mat", _FP),
+                ("tri_order", _UP), ("sph_order", _UP), ("pl_order", _UP),
+                ("ntri", C.c_uint32), ("nsph", C.c_uint32), ("npl", C.c_uint32),
+                ("lights", _FP), ("nlights", C.c_uint32)]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [("primary", C.c_uint64), ("shadow", C.c_uint64), ("secondary", C.c_uint64),
+                ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class rt_bvh_info(C.Structure):
+    _fields_ = [("node_pairs", C.c_uint32), ("leaves", C.c_uint32), ("max_depth", C.c_uint32), ("max_leaf", C.c_uint32),
+                ("bvh_prims", C.c_uint32), ("list_prims", C.c_uint32), ("build_ms", C.c_double), ("sah_cost", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class rth_config_info(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("maxdepth", C.c_uint32), ("maxverts", C.c_uint32),
+                ("ntri", C.c_uint32), ("nsph", C.c_uint32), ("npl", C.c_uint32), ("nlights", C.c_uint32),
+                ("camera_position", C.c_float * 3), ("camera_look_at", C.c_float * 3), ("camera_up", C.c_float * 3),
+                ("camera_fov", C.c_float), ("ambient", C.c_float * 3)]
+
+
+# Every symbol include/rt_amd.h and include/rt_host.h declare, with its signature.
+_SIGNATURES = {
+    "rt_frame_from_camera": (C.c_int, [_FP, _FP, _FP, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, _FP, C.POINTER(rt_frame)]),
+    "rt_init": (C.c_int, [C.c_int]),
+    "rt_upload_scene": (C.c_int, [C.POINTER(rt_scene)]),
+    "rt_get_bvh_info": (C.c_int, [C.POINTER(rt_bvh_info)]),
+    "rt_scene_blob": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "rt_adopt_scene_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rt_render": (C.c_int, [C.POINTER(rt_frame), C.c_void_p, C.POINTER(rt_stats), C.c_int]),
+    "rt_render_tiles": (C.c_int, [C.POINTER(rt_frame), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(rt_stats), C.c_int]),
+    "rt_shard_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rt_assemble_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rt_stream": (C.c_void_p, []),
+    "rt_synchronize": (C.c_int, []),
+    "rt_last_error": (C.c_char_p, []),
+    "rt_shutdown": (None, []),
+    "rth_load_config_file": (C.c_void_p, [C.c_char_p]),
+    "rth_parse_config_text": (C.c_void_p, [C.c_char_p]),
+    "rth_config_free": (None, [C.c_void_p]),
+    "rth_config_get_info": (C.c_int, [C.c_void_p, C.POINTER(rth_config_info)]),
+    "rth_config_output_file": (C.c_char_p, [C.c_void_p]),
+    "rth_config_set_size": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rth_config_scene": (C.c_int, [C.c_void_p, C.POINTER(rt_scene)]),
+    "rth_config_frame": (C.c_int, [C.c_void_p, C.POINTER(rt_frame)]),
+    "rth_image_compare": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rth_pack_scene": (C.c_int, [C.POINTER(rt_scene), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(rt_bvh_info)]),
+    "rth_free": (None, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded librt_amd.so.  Raises when it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here = header and library disagree
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(lib().rt_last_error().decode(errors="replace"))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_FP) if a.size else C.cast(None, _FP)
+
+
+# ------------------------------------------------------------------------------------ scene model
+class Config:
+    """Config of config_builder.rs:14-24 (opaque handle into the C++ twin)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rth_config_free(self._h)
+            self._h = None
+
+    def _info(self):
+        i = rth_config_info()
+        _check(lib().rth_config_get_info(self._h, C.byref(i)))
+        return i
+
+    width = property(lambda self: self._info().width)
+    height = property(lambda self: self._info().height)
+    maxdepth = property(lambda self: self._info().maxdepth)
+    maxverts = property(lambda self: self._info().maxverts)
+    ambient = property(lambda self: tuple(self._info().ambient))
+
+    @property
+    def output_file(self):
+        return lib().rth_config_output_file(self._h).decode()
+
+    @property
+    def camera(self):
+        i = self._info()
+        return {"position": tuple(i.camera_position), "look_at": tuple(i.camera_look_at), "up": tuple(i.camera_up), "fov": i.camera_fov}
+
+    def counts(self):
+        i = self._info()
+        return {"ntri": i.ntri, "nsph": i.nsph, "npl": i.npl, "nlights": i.nlights}
+
+    def set_size(self, width, height):
+        """What editing the `size` line does (the 3840x2160 dragon configuration)."""
+        _check(lib().rth_config_set_size(self._h, width, height))
+
+    def scene(self):
+        s = rt_scene()
+        _check(lib().rth_config_scene(self._h, C.byref(s)))
+        s._owner = self          # the arrays live inside the config
+        return s
+
+    def frame(self):
+        f = rt_frame()
+        _check(lib().rth_config_frame(self._h, C.byref(f)))
+        return f
+
+
+class ParsedConfigState:
+    """ParsedConfigState of config_builder.rs:111-150."""
+
+    def load_config_file(self, file_path):
+        h = lib().rth_load_config_file(os.fsencode(file_path))
+        if not h:
+            raise RtError(lib().rt_last_error().decode(errors="replace"))
+        return Config(h)
+
+    def parse_text(self, text):
+        h = lib().rth_parse_config_text(text.encode())
+        if not h:
+            raise RtError(lib().rt_last_error().decode(errors="replace"))
+        return Config(h)
+
+
+class SceneArrays:
+    """A scene given directly as arrays (synthetic meshes too large for a text file).
+
+    Keeps the numpy buffers alive for as long as the rt_scene that points into them.
+    """
+
+    def __init__(self, tri=None, tri_mat=None, spheres=None, sph_mat=None, planes=None, pl_mat=None, lights=None,
+                 tri_order=None, sph_order=None, pl_order=None):
+        z = np.zeros((0,), dtype=np.float32)
+        tri = _f32(tri).reshape(-1, 9) if tri is not None else z.reshape(0, 9)
+        self.v0, self.v1, self.v2 = _f32(tri[:, 0:3]), _f32(tri[:, 3:6]), _f32(tri[:, 6:9])
+        sph = _f32(spheres).reshape(-1, 4) if spheres is not None else z.reshape(0, 4)
+        self.sc, self.sr = _f32(sph[:, 0:3]), _f32(sph[:, 3])
+        pl = _f32(planes).reshape(-1, 6) if planes is not None else z.reshape(0, 6)
+        self.pp, self.pn = _f32(pl[:, 0:3]), _f32(pl[:, 3:6])
+
+        def mats(m, n):
+            m = _f32(m if m is not None else z).reshape(-1, 7) if n else z.reshape(0, 7)
+            if n and m.shape[0] == 1:
+                m = np.repeat(m, n, axis=0)
+            assert m.shape[0] == n, "one material (7 floats) per shape, or a single one for all"
+            return _f32(m)
+
+        self.tm, self.sm, self.pm = mats(tri_mat, len(tri)), mats(sph_mat, len(sph)), mats(pl_mat, len(pl))
+        self.lights = _f32(lights).reshape(-1, 7) if lights is not None else z.reshape(0, 7)
+        self.orders = [None if o is None else np.ascontiguousarray(o, dtype=np.uint32) for o in (tri_order, sph_order, pl_order)]
+        s = rt_scene()
+        s.tri_v0, s.tri_v1, s.tri_v2, s.tri_mat = _fp(self.v0), _fp(self.v1), _fp(self.v2), _fp(self.tm)
+        s.sph_center, s.sph_radius, s.sph_mat = _fp(self.sc), _fp(self.sr), _fp(self.sm)
+        s.pl_point, s.pl_normal, s.pl_mat = _fp(self.pp), _fp(self.pn), _fp(self.pm)
+        for name, o in zip(("tri_order", "sph_order", "pl_order"), self.orders):
+            setattr(s, name, o.ctypes.data_as(_UP) if o is not None else C.cast(None, _UP))
+        s.ntri, s.nsph, s.npl = len(tri), len(sph), len(pl)
+        s.lights, s.nlights = _fp(self.lights), len(self.lights)
+        # The struct only holds raw pointers: tie the buffers' lifetime to it as well, so that
+        # `SceneArrays(...).c` stays valid after the wrapper object is gone.
+        s._buffers = (self.v0, self.v1, self.v2, self.sc, self.sr, self.pp, self.pn, self.tm, self.sm, self.pm, self.lights, self.orders)
+        self.c = s
+
+
+def frame_from_camera(position, look_at, up, fov, width, height, maxdepth, ambient):
+    p, l, u, a = _f32(position), _f32(look_at), _f32(up), _f32(ambient)
+    f = rt_frame()
+    _check(lib().rt_frame_from_camera(_fp(p), _fp(l), _fp(u), float(fov), width, height, maxdepth, _fp(a), C.byref(f)))
+    return f
+
+
+def pack_scene_host(scene):
+    """Host-only build of the device blob: (bytes as np.uint8 array, bvh info dict)."""
+    blob, n, info = C.c_void_p(), C.c_size_t(), rt_bvh_info()
+    _check(lib().rth_pack_scene(C.byref(scene), C.byref(blob), C.byref(n), C.byref(info)))
+    try:
+        out = np.ctypeslib.as_array(C.cast(blob, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
+    finally:
+        lib().rth_free(blob)
+    return out, info.as_dict()
+
+
+# ------------------------------------------------------------------------------------ images
+class Image:
+    """Image of imgcomparator/mod.rs:21-40: width, height, packed 0x??RRGGBB pixels."""
+
+    def __init__(self, width, height, data):
+        self.width, self.height = int(width), int(height)
+        self.data = np.ascontiguousarray(data, dtype=np.uint32).reshape(-1)
+
+    def pixels(self):
+        return self.data.reshape(self.height, self.width)
+
+    @staticmethod
+    def compare(img1, img2):
+        """(number of pixels with a channel differing by more than 1, difference image)."""
+        n = max(img1.data.size, 1)
+        diff = np.zeros(n, dtype=np.uint32)
+        count = C.c_uint64()
+        _check(lib().rth_image_compare(img1.data.ctypes.data, img1.width, img1.height, img2.data.ctypes.data, img2.width, img2.height,
+                                       diff.ctypes.data, C.byref(count)))
+        return int(count.value), Image(img1.width, img1.height, diff[:img1.data.size])
+
+
+def extract_rgb(pixel):
+    return (pixel >> 16) & 0xFF, (pixel >> 8) & 0xFF, pixel & 0xFF
+
+
+def file_to_image(path):
+    from PIL import Image as PILImage
+    im = np.asarray(PILImage.open(path).convert("RGB"), dtype=np.uint32)
+    return Image(im.shape[1], im.shape[0], (im[..., 0] << 16) | (im[..., 1] << 8) | im[..., 2])
+
+
+def save_image(img, path):
+    from PIL import Image as PILImage
+    p = img.pixels()
+    rgb = np.stack([(p >> 16) & 0xFF, (p >> 8) & 0xFF, p & 0xFF], axis=-1).astype(np.uint8)
+    PILImage.fromarray(rgb, "RGB").save(path)
+
+
+# ------------------------------------------------------------------------------------ renderer
+_bound_device = None
+
+
+def init(device=0):
+    """Binds this process to one GPU (one process per GPU)."""
+    global _bound_device
+    _check(lib().rt_init(int(device)))
+    _bound_device = int(device)
+
+
+def shutdown():
+    global _bound_device
+    if _lib is not None:
+        _lib.rt_shutdown()
+    _bound_device = None
+
+
+def upload_scene(scene):
+    _check(lib().rt_upload_scene(C.byref(scene)))
+    info = rt_bvh_info()
+    _check(lib().rt_get_bvh_info(C.byref(info)))
+    return info.as_dict()
+
+
+def scene_blob():
+    p, n = C.c_void_p(), C.c_size_t()
+    _check(lib().rt_scene_blob(C.byref(p), C.byref(n)))
+    return p.value, n.value
+
+
+def adopt_scene_blob(device_ptr, nbytes):
+    _check(lib().rt_adopt_scene_blob(C.c_void_p(device_ptr), nbytes))
+
+
+def shard_rows(height, shard, nshards, tile_rows=TILE_ROWS):
+    return int(lib().rt_shard_rows(height, shard, nshards, tile_rows))
+
+
+def render(frame, count_work=False):
+    """Whole frame into host memory: (pixels[H, W] uint32, stats dict)."""
+    out = np.empty((frame.height, frame.width), dtype=np.uint32)
+    st = rt_stats()
+    _check(lib().rt_render(C.byref(frame), out.ctypes.data, C.byref(st), int(bool(count_work))))
+    return out, st.as_dict()
+
+
+def render_tiles(frame, shard, nshards, device_ptr, tile_rows=TILE_ROWS, want_stats=False, count_work=False):
+    """One shard's row tiles into a device buffer (compact rows)."""
+    st = rt_stats()
+    _check(lib().rt_render_tiles(C.byref(frame), shard, nshards, tile_rows, C.c_void_p(device_ptr),
+                                 C.byref(st) if (want_stats or count_work) else None, int(bool(count_work))))
+    return st.as_dict() if (want_stats or count_work) else None
+
+
+def assemble_tiles(gathered_ptr, stride_rows, nshards, width, height, frame_ptr, tile_rows=TILE_ROWS):
+    _check(lib().rt_assemble_tiles(C.c_void_p(gathered_ptr), stride_rows, nshards, tile_rows, width, height, C.c_void_p(frame_ptr)))
+
+
+def synchronize():
+    _check(lib().rt_synchronize())
+
+
+def stream():
+    return lib().rt_stream()
+
+
+class RayTracer:
+    """RayTracer of raytracer.rs:16-83 on one MI355X."""
+
+    def __init__(self, config, device=None):
+        if _bound_device is None:
+            init(0 if device is None else device)
+        self.config = config
+        self._scene = config.scene() if isinstance(config, Config) else config.c
+        self.bvh_info = upload_scene(self._scene)          # RayTracer::new builds the tree (raytracer.rs:32)
+        self.last_stats = None
+
+    @classmethod
+    def new(cls, config):
+        return cls(config)
+
+    def render(self, count_work=False):
+        pixels, self.last_stats = render(self.config.frame(), count_work=count_work)
+        return Image(pixels.shape[1], pixels.shape[0], pixels)
+
+    def get_output_path(self):
+        return self.config.output_file

@@ -1,0 +1,225 @@
+// bvh_build.cpp -- host builder of the GPU bounding volume hierarchy.
+//
+// Takes the place of Bvh::build_par (reference src/raytracer/raytracer.rs:32; the bvh crate
+// builds a SAH binary tree with one shape per leaf).  In the reference the tree only selects
+// candidates that are then tested exactly (raytracer.rs:110-120), so any tree whose culling
+// is conservative gives the same image; this one is laid out for the GPU instead:
+// binned-SAH binary tree, up to 8 shapes per leaf, stored as 64-byte child-pair records
+// (layout.h), leaves contiguous in a reordered shape array.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <omp.h>
+
+namespace rtb {
+
+namespace {
+
+constexpr int NBINS = 32;
+constexpr float COST_TRAVERSE = 1.0f;   // one node pair fetch + two slab tests
+constexpr float COST_SHAPE = 1.0f;      // one exact shape test
+constexpr uint32_t PARALLEL_MIN = 8192; // subtrees above this size become OpenMP tasks
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -lo[k]; } }
+    void grow(const float* l, const float* h) {
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]); }
+    }
+    void grow(const Box& b) { grow(b.lo, b.hi); }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0.0f) || !(dy >= 0.0f) || !(dz >= 0.0f)) return 0.0f;
+        // Huge extents (a sphere of radius 1e4 next to unit spheres) overflow nothing in float,
+        // but keep the arithmetic in double so that ratios stay meaningful.
+        return (float)((double)dx * dy + (double)dy * dz + (double)dz * dx);
+    }
+};
+
+struct Builder {
+    const float* lo; const float* hi;      // n x 3 shape boxes
+    uint32_t n;
+    uint32_t depth_limit;
+    float pad_abs;
+    std::vector<uint32_t> idx;             // permutation being partitioned
+    std::vector<float> ctr;                // n x 3 centroids
+    std::vector<rtl::NodePair> pairs;
+    std::atomic<uint32_t> next_pair{0};
+    std::atomic<uint32_t> n_leaves{0}, max_depth{0}, max_leaf{0};
+
+    Box bounds(uint32_t first, uint32_t count) const {
+        Box b; b.reset();
+        for (uint32_t i = first; i < first + count; i++) b.grow(lo + 3 * (size_t)idx[i], hi + 3 * (size_t)idx[i]);
+        return b;
+    }
+
+    void write_child(rtl::ChildBox& c, const Box& b, uint32_t ref, uint32_t count) {
+        for (int k = 0; k < 3; k++) {
+            // Outward padding keeps culling conservative: against rounding in the slab test, and
+            // against exact shape tests that accept rays passing a rounding error outside the shape.
+            float m = std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
+            float pad = m * 4e-7f + pad_abs;
+            c.lo[k] = b.lo[k] - pad; c.hi[k] = b.hi[k] + pad;
+        }
+        c.ref = ref; c.count = count;
+    }
+
+    static void atomic_max(std::atomic<uint32_t>& a, uint32_t v) {
+        uint32_t cur = a.load(std::memory_order_relaxed);
+        while (cur < v && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+    }
+
+    uint32_t make_leaf(uint32_t first, uint32_t count, uint32_t depth) {
+        n_leaves.fetch_add(1, std::memory_order_relaxed);
+        atomic_max(max_depth, depth);
+        atomic_max(max_leaf, count);
+        // Shapes inside a leaf in file order: the scan inside a leaf then breaks ties like a file-order scan.
+        std::sort(idx.begin() + first, idx.begin() + first + count);
+        return rtl::make_leaf_ref(first, count);
+    }
+
+    // Returns the split position (first < mid < first + count) or 0 when a leaf is cheaper.
+    uint32_t choose_split(uint32_t first, uint32_t count, const Box& nb, bool force_median) {
+        Box cb; cb.reset();
+        for (uint32_t i = first; i < first + count; i++) { const float* c = &ctr[3 * (size_t)idx[i]]; cb.grow(c, c); }
+        int axis_by_extent = 0;
+        for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > cb.hi[axis_by_extent] - cb.lo[axis_by_extent]) axis_by_extent = k;
+
+        auto median_split = [&](int axis) -> uint32_t {
+            uint32_t mid = first + count / 2;
+            std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + first + count,
+                             [&](uint32_t p, uint32_t q) {
+                                 float a = ctr[3 * (size_t)p + axis], b = ctr[3 * (size_t)q + axis];
+                                 return a != b ? a < b : p < q;
+                             });
+            return mid;
+        };
+        if (force_median) return median_split(axis_by_extent);
+
+        float parent_area = nb.half_area();
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1, best_bin = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            float c0 = cb.lo[axis], c1 = cb.hi[axis];
+            if (!(c1 > c0)) continue;
+            float scale = (float)NBINS / (c1 - c0);
+            Box bb[NBINS]; uint32_t bc[NBINS];
+            for (int b = 0; b < NBINS; b++) { bb[b].reset(); bc[b] = 0; }
+            for (uint32_t i = first; i < first + count; i++) {
+                uint32_t s = idx[i];
+                int b = (int)((ctr[3 * (size_t)s + axis] - c0) * scale);
+                b = std::min(std::max(b, 0), NBINS - 1);
+                bb[b].grow(lo + 3 * (size_t)s, hi + 3 * (size_t)s); bc[b]++;
+            }
+            float right_area[NBINS]; uint32_t right_cnt[NBINS];
+            Box acc; acc.reset(); uint32_t cnt = 0;
+            for (int b = NBINS - 1; b >= 1; b--) { acc.grow(bb[b]); cnt += bc[b]; right_area[b] = acc.half_area(); right_cnt[b] = cnt; }
+            acc.reset(); cnt = 0;
+            for (int b = 0; b < NBINS - 1; b++) {
+                acc.grow(bb[b]); cnt += bc[b];
+                if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                float cost = acc.half_area() * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+            }
+        }
+        if (best_axis < 0) {
+            // All centroids coincide: nothing to bin.  Keep a leaf if it fits, else halve by index.
+            if (count <= rtl::MAX_LEAF) return 0;
+            return first + count / 2;
+        }
+        float split_cost = COST_TRAVERSE + COST_SHAPE * (parent_area > 0.0f ? best_cost / parent_area : (float)count);
+        float leaf_cost = COST_SHAPE * (float)count;
+        if (count <= rtl::MAX_LEAF && leaf_cost <= split_cost) return 0;
+        float c0 = cb.lo[best_axis], c1 = cb.hi[best_axis];
+        float scale = (float)NBINS / (c1 - c0);
+        auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t s) {
+            int b = (int)((ctr[3 * (size_t)s + best_axis] - c0) * scale);
+            b = std::min(std::max(b, 0), NBINS - 1);
+            return b <= best_bin;
+        });
+        uint32_t mid = (uint32_t)(it - idx.begin());
+        if (mid == first || mid == first + count) return median_split(axis_by_extent);
+        return mid;
+    }
+
+    // Builds the subtree over idx[first, first+count) and returns its reference.
+    uint32_t build(uint32_t first, uint32_t count, uint32_t depth, const Box& nb) {
+        if (count == 1) return make_leaf(first, 1, depth);
+        // Depth budget: a balanced subtree over `count` shapes needs ceil(log2(count / MAX_LEAF)) more levels.
+        uint32_t need = 0; while (((uint64_t)rtl::MAX_LEAF << need) < count) need++;
+        bool force_median = depth + need + 1 >= depth_limit;
+        if (force_median && count <= rtl::MAX_LEAF) return make_leaf(first, count, depth);
+        uint32_t mid = choose_split(first, count, nb, force_median);
+        if (mid == 0) return make_leaf(first, count, depth);
+        uint32_t me = next_pair.fetch_add(1, std::memory_order_relaxed);
+        uint32_t nl = mid - first, nr = first + count - mid;
+        Box bl = bounds(first, nl), br = bounds(mid, nr);
+        uint32_t rl = 0, rr = 0;
+        if (count >= PARALLEL_MIN) {
+#pragma omp task shared(rl) firstprivate(first, nl, depth, bl)
+            rl = build(first, nl, depth + 1, bl);
+#pragma omp task shared(rr) firstprivate(mid, nr, depth, br)
+            rr = build(mid, nr, depth + 1, br);
+#pragma omp taskwait
+        } else {
+            rl = build(first, nl, depth + 1, bl);
+            rr = build(mid, nr, depth + 1, br);
+        }
+        rtl::NodePair& p = pairs[me];
+        write_child(p.c[0], bl, rl, (rl & rtl::REF_LEAF) ? (rl & 7u) + 1u : 0u);
+        write_child(p.c[1], br, rr, (rr & rtl::REF_LEAF) ? (rr & 7u) + 1u : 0u);
+        return me;
+    }
+};
+
+double sah_of(const std::vector<rtl::NodePair>& pairs, uint32_t ref, double area_root, double area_self) {
+    if (ref & rtl::REF_LEAF) return COST_SHAPE * ((ref & 7u) + 1u) * area_self / area_root;
+    const rtl::NodePair& p = pairs[ref];
+    double c = COST_TRAVERSE * area_self / area_root;
+    for (int k = 0; k < 2; k++) {
+        double dx = (double)p.c[k].hi[0] - p.c[k].lo[0], dy = (double)p.c[k].hi[1] - p.c[k].lo[1], dz = (double)p.c[k].hi[2] - p.c[k].lo[2];
+        c += sah_of(pairs, p.c[k].ref, area_root, dx * dy + dy * dz + dz * dx);
+    }
+    return c;
+}
+
+}  // namespace
+
+bool build_bvh(const float* lo, const float* hi, uint32_t n, uint32_t depth_limit, float pad_abs, BvhResult* out, std::string* err) {
+    out->pairs.clear(); out->order.clear();
+    out->root_ref = rtl::REF_EMPTY; out->max_depth = 0; out->max_leaf = 0; out->n_leaves = 0; out->sah_cost = 0.0;
+    if (n == 0) return true;
+    if (n > rtl::MAX_TREE_SHAPES) { *err = "too many shapes for the tree's leaf references"; return false; }
+    if (depth_limit < 8) { *err = "depth limit too small"; return false; }
+    {
+        uint32_t need = 0; while (((uint64_t)rtl::MAX_LEAF << need) < n) need++;
+        if (need + 2 > depth_limit) { *err = "scene too large for the traversal stack depth"; return false; }
+    }
+    Builder b;
+    b.lo = lo; b.hi = hi; b.n = n; b.depth_limit = depth_limit; b.pad_abs = pad_abs;
+    b.idx.resize(n); b.ctr.resize(3 * (size_t)n);
+    for (uint32_t i = 0; i < n; i++) {
+        b.idx[i] = i;
+        for (int k = 0; k < 3; k++) b.ctr[3 * (size_t)i + k] = 0.5f * lo[3 * (size_t)i + k] + 0.5f * hi[3 * (size_t)i + k];
+    }
+    b.pairs.resize(n > 1 ? n - 1 : 1);
+    Box root = b.bounds(0, n);
+    uint32_t root_ref = 0;
+#pragma omp parallel
+#pragma omp single
+    root_ref = b.build(0, n, 0, root);
+    b.pairs.resize(b.next_pair.load());
+    out->pairs.swap(b.pairs);
+    out->order.swap(b.idx);
+    out->root_ref = root_ref;
+    out->max_depth = b.max_depth.load(); out->max_leaf = b.max_leaf.load(); out->n_leaves = b.n_leaves.load();
+    double ar = root.half_area();
+    out->sah_cost = ar > 0.0 ? sah_of(out->pairs, root_ref, ar, ar) : 0.0;
+    return true;
+}
+
+}  // namespace rtb

@@ -1,0 +1,32 @@
+// device_types.h -- kernel argument blocks, shared by render_kernels.hip and rt_api.cpp.
+#ifndef RT_DEVICE_TYPES_H
+#define RT_DEVICE_TYPES_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Pointers into the resident scene blob (layout.h).
+struct DevScene {
+    const float4* nodes;    // 4 float4 per node pair
+    const float4* tree;     // 3 float4 per tree shape, leaves contiguous
+    const float4* list;     // 3 float4 per always-tested shape
+    const float4* mats;     // 2 float4 per material
+    const float4* lights;   // 2 float4 per light
+    uint32_t n_list, n_lights, root_ref, pad;
+};
+
+// rt_frame plus the shard this launch renders.
+struct DevFrame {
+    float pos[3], cv[3], right[3], up[3];
+    float pw, ph, w2, h2;
+    uint32_t width, height, maxdepth;
+    float ambient[3];
+    uint32_t shard, nshards, tile_rows, local_rows;
+};
+
+extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, uint32_t* d_out, float4* d_fold,
+                                        unsigned long long* d_counters, int stack_depth, int count, hipStream_t stream);
+extern "C" hipError_t rtk_launch_assemble(const uint32_t* d_gathered, uint32_t stride_rows, uint32_t nshards, uint32_t tile_rows,
+                                          uint32_t width, uint32_t height, uint32_t* d_frame, hipStream_t stream);
+
+#endif

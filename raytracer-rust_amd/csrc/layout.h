@@ -1,0 +1,63 @@
+// layout.h -- device-side scene layout shared by the host builder and the HIP kernels.
+//
+// Everything the kernels read lives in ONE contiguous device blob (so that a scene can be
+// replicated to another GPU with a single broadcast):
+//
+//   [BlobHeader 256 B][node pairs][tree shapes][list shapes][materials][lights]
+//
+// every section 256-byte aligned.
+//
+//   node pair  64 B  two 32-byte child boxes side by side: {lo.xyz, ref} {hi.xyz, count} per
+//                    child.  One 64-byte fetch yields both boxes a traversal step needs.
+//   shape      48 B  three float4.  q0.w carries kind | material << 2, q1.w the shape's
+//                    position in the scene file (tie break), q2.w is spare.
+//                      triangle: q0.xyz = v0, q1.xyz = v1, q2.xyz = v2   (raw vertices: the
+//                                edges are recomputed per test, as shape.rs:149-150 does)
+//                      sphere:   q0.xyz = center, q1.x = radius
+//                      plane:    q0.xyz = point,  q2.xyz = unit normal
+//   material   32 B  {diffuse.rgb, shininess} {specular.rgb, 0}
+//   light      32 B  {vec.xyz, kind} {colour.rgb, 0}     kind 0 = point, 1 = directional
+#ifndef RT_LAYOUT_H
+#define RT_LAYOUT_H
+
+#include <stdint.h>
+
+namespace rtl {
+
+constexpr uint32_t KIND_SPHERE = 0, KIND_TRIANGLE = 1, KIND_PLANE = 2;
+
+// Child reference.  Inner: index of a node pair (bit 31 clear).  Leaf: bit 31 set,
+// bits 30..3 = first shape of the leaf in the tree-shape array, bits 2..0 = count - 1.
+constexpr uint32_t REF_LEAF = 0x80000000u;
+constexpr uint32_t REF_EMPTY = 0xFFFFFFFFu;   // never produced for a real leaf (would need first = 2^28 - 1)
+constexpr uint32_t MAX_LEAF = 8;
+constexpr uint32_t MAX_TREE_SHAPES = (1u << 28) - 2;
+
+inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return REF_LEAF | (first << 3) | (count - 1); }
+
+struct ChildBox { float lo[3]; uint32_t ref; float hi[3]; uint32_t count; };
+struct NodePair { ChildBox c[2]; };
+static_assert(sizeof(NodePair) == 64, "node pair must be 64 bytes");
+
+struct ShapeRec { float q0[3]; uint32_t kind_mat; float q1[3]; uint32_t order; float q2[3]; uint32_t spare; };
+static_assert(sizeof(ShapeRec) == 48, "shape record must be 48 bytes");
+
+struct MaterialRec { float diffuse[3]; float shininess; float specular[3]; float pad; };
+struct LightRec { float v[3]; float kind; float color[3]; float pad; };
+
+constexpr uint32_t BLOB_MAGIC = 0x52544231u;   // "RTB1"
+
+struct BlobHeader {
+    uint32_t magic, version;
+    uint64_t total_bytes;
+    uint64_t off_nodes, off_tree_shapes, off_list_shapes, off_materials, off_lights;
+    uint32_t n_pairs, n_tree_shapes, n_list_shapes, n_materials, n_lights;
+    uint32_t root_ref;
+    uint32_t max_depth, max_leaf, n_leaves;
+    float sah_cost;
+    uint32_t pad[64 - 24];
+};
+static_assert(sizeof(BlobHeader) == 256, "blob header must be 256 bytes");
+
+}  // namespace rtl
+#endif

@@ -1,0 +1,405 @@
+// render_kernels.hip -- the per-pixel render loop as gfx950 kernels.
+//
+// One thread renders one pixel start to finish: camera ray generation, closest hit over the
+// always-tested list and the tree, one shadow ray per light, Lambert + Blinn-Phong shading and
+// the bounded mirror recursion of the reference, unrolled into a forward pass that records one
+// {local colour, material} per depth and a backward fold (so that the float operations happen
+// in the reference's order).  A wavefront covers an 8x8 pixel tile.
+//
+// Arithmetic contract.  Everything that decides a pixel is IEEE binary32 evaluated in exactly
+// the order the reference evaluates it, with no multiply-add fusion (this file is compiled
+// with -ffp-contract=off and says so again below), correctly rounded division and square
+// root, and denormals preserved:
+//   dot(a,b)     = (a.x*b.x + a.y*b.y) + a.z*b.z
+//   cross(a,b)   = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)
+//   normalize(a) = a * (1.0f / sqrtf(dot(a,a)))
+// Box culling is the only place with freedom: it is conservative (padded boxes, slack on the
+// pruning distance), so it never removes a shape the exact test would accept.
+//
+// Reference code each part follows (paths relative to the reference tree):
+//   pixel loop / ray generation   src/raytracer/raytracer.rs:57-72
+//   quantise                      src/raytracer/raytracer.rs:85-91
+//   closest hit                   src/raytracer/raytracer.rs:109-120
+//   shadow test and guards        src/raytracer/raytracer.rs:126-159
+//   shading                       src/raytracer/raytracer.rs:160-181
+//   reflection                    src/raytracer/raytracer.rs:183-196
+//   sphere / plane / triangle     src/raytracer/config/shape.rs:72-96, 112-132, 149-191
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+#include "layout.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+using rtl::KIND_PLANE;
+using rtl::KIND_SPHERE;
+using rtl::KIND_TRIANGLE;
+using rtl::REF_EMPTY;
+using rtl::REF_LEAF;
+
+constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
+constexpr uint32_t LIST_FLAG = 0x80000000u;
+constexpr float INF = __builtin_huge_valf();
+
+// ------------------------------------------------------------------ vector primitives
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 v3(const float4 q) { return v3(q.x, q.y, q.z); }
+__device__ __forceinline__ V3 v3(const float* p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 vadd(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 vscale(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 vcmul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 vneg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float vdot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 vcross(V3 a, V3 b) {
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float vnorm(V3 a) { return sqrtf(vdot(a, a)); }
+__device__ __forceinline__ V3 vnormalize(V3 a) { float inv = 1.0f / vnorm(a); return vscale(a, inv); }
+
+struct Counters { uint32_t nodes, prims, shadow, secondary; };
+
+// ------------------------------------------------------------------ exact shape tests
+// Each returns whether the reference's test yields Some(..) and the distance it would carry.
+
+__device__ __forceinline__ bool test_triangle(V3 v0, V3 v1, V3 v2, V3 o, V3 d, float* t_out) {   // shape.rs:149-176
+    V3 e1 = vsub(v1, v0);
+    V3 e2 = vsub(v2, v0);
+    V3 h = vcross(d, e2);
+    float a = vdot(e1, h);
+    if (fabsf(a) < 1e-6f) return false;
+    float f = 1.0f / a;
+    V3 s = vsub(o, v0);
+    float u = f * vdot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    V3 q = vcross(s, e1);
+    float v = f * vdot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = f * vdot(e2, q);
+    if (t < 0.0f) return false;
+    *t_out = t;
+    return true;
+}
+
+__device__ __forceinline__ bool test_sphere(V3 c, float radius, V3 o, V3 d, float* t_out) {      // shape.rs:72-83
+    V3 oc = vsub(o, c);
+    float half_b = vdot(oc, d);
+    float cc = vdot(oc, oc) - radius * radius;
+    float disc = half_b * half_b - cc;
+    if (disc < 0.0f) return false;
+    float t = -half_b - sqrtf(disc);
+    if (t < 0.0f) return false;
+    *t_out = t;
+    return true;
+}
+
+__device__ __forceinline__ bool test_plane(V3 p, V3 n, V3 o, V3 d, float* t_out) {               // shape.rs:112-120
+    float denom = vdot(n, d);
+    if (fabsf(denom) < 1e-6f) return false;
+    float t = vdot(vsub(p, o), n) / denom;
+    if (t < 0.0f) return false;
+    *t_out = t;
+    return true;
+}
+
+__device__ __forceinline__ bool test_shape(const float4 q0, const float4 q1, const float4 q2, V3 o, V3 d, float* t_out) {
+    uint32_t kind = __float_as_uint(q0.w) & 3u;
+    if (kind == KIND_TRIANGLE) return test_triangle(v3(q0), v3(q1), v3(q2), o, d, t_out);
+    if (kind == KIND_SPHERE) return test_sphere(v3(q0), q1.x, o, d, t_out);
+    return test_plane(v3(q0), v3(q2), o, d, t_out);
+}
+
+// is_back_face of the reference's Intersection: only triangles can be back faces (shape.rs:94,131,181).
+__device__ __forceinline__ bool shape_back_face(const float4 q0, const float4 q1, const float4 q2, V3 d) {
+    uint32_t kind = __float_as_uint(q0.w) & 3u;
+    if (kind != KIND_TRIANGLE) return false;
+    V3 e1 = vsub(v3(q1), v3(q0)), e2 = vsub(v3(q2), v3(q0));
+    V3 n = vnormalize(vcross(e1, e2));
+    return vdot(n, d) > 0.0f;
+}
+
+// ------------------------------------------------------------------ box culling (conservative)
+// Padded boxes, NaN-dropping min/max (a 0 * inf on a slab the origin lies on removes that
+// slab's constraint) and a relative slack on the far side cover the rounding of this test.
+__device__ __forceinline__ bool slab(const float4 lo, const float4 hi, V3 o, V3 inv, float tlim, float* tnear) {
+    float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+    float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+    float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tlim));
+    *tnear = tn;
+    return tn <= tf * 1.000001f;
+}
+
+// Pruning bound for a closest hit at computed distance t: shapes whose computed distance could
+// still come out smaller (their exact test rounds differently) must stay reachable.
+__device__ __forceinline__ float prune_limit(float t) { return t * 1.0005f + 1e-4f; }
+
+struct Best { float t; uint32_t prim; uint32_t order; };
+
+// raytracer.rs:113-120: smallest distance wins; on exactly equal distances the shape that
+// comes first in the scene file wins.
+__device__ __forceinline__ void consider(Best* b, float t, uint32_t prim, uint32_t order) {
+    bool take = (b->prim == NO_PRIM) || (b->t > t) || (b->t == t && order < b->order);
+    if (take) { b->t = t; b->prim = prim; b->order = order; }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint32_t* stack, Best* best, Counters* cnt) {
+    best->t = INF; best->prim = NO_PRIM; best->order = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < sc.n_list; i++) {
+        const float4 q0 = sc.list[3 * i], q1 = sc.list[3 * i + 1], q2 = sc.list[3 * i + 2];
+        float t;
+        if (COUNT) cnt->prims++;
+        if (test_shape(q0, q1, q2, o, d, &t)) consider(best, t, LIST_FLAG | i, __float_as_uint(q1.w));
+    }
+    uint32_t cur = sc.root_ref;
+    if (cur == REF_EMPTY) return;
+    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float tlim = best->prim == NO_PRIM ? INF : prune_limit(best->t);
+    uint32_t sp = 0;
+    for (;;) {
+        if (!(cur & REF_LEAF)) {
+            const float4* n = sc.nodes + 4 * (size_t)cur;
+            const float4 lo0 = n[0], hi0 = n[1], lo1 = n[2], hi1 = n[3];
+            float t0, t1;
+            bool h0 = slab(lo0, hi0, o, inv, tlim, &t0);
+            bool h1 = slab(lo1, hi1, o, inv, tlim, &t1);
+            if (COUNT) cnt->nodes += 2;
+            uint32_t r0 = __float_as_uint(lo0.w), r1 = __float_as_uint(lo1.w);
+            if (h0 && h1) {
+                bool swap = t1 < t0;
+                stack[sp * 64] = swap ? r0 : r1; sp++;
+                cur = swap ? r1 : r0;
+            } else if (h0) cur = r0;
+            else if (h1) cur = r1;
+            else { if (sp == 0) break; sp--; cur = stack[sp * 64]; }
+        } else {
+            uint32_t first = (cur & ~REF_LEAF) >> 3, count = (cur & 7u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                const float4* p = sc.tree + 3 * (size_t)(first + k);
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                float t;
+                if (COUNT) cnt->prims++;
+                if (test_shape(q0, q1, q2, o, d, &t)) {
+                    consider(best, t, first + k, __float_as_uint(q1.w));
+                    tlim = prune_limit(best->t);
+                }
+            }
+            if (sp == 0) break; sp--; cur = stack[sp * 64];
+        }
+    }
+}
+
+// raytracer.rs:143-159 for one candidate.
+__device__ __forceinline__ bool occludes(const float4 q0, const float4 q1, const float4 q2, V3 o, V3 d, bool hit_back, bool point_light,
+                                         float light_dist) {
+    float t;
+    if (!test_shape(q0, q1, q2, o, d, &t)) return false;
+    if (t < 1e-6f) return false;
+    if (hit_back && shape_back_face(q0, q1, q2, d)) return false;
+    if (point_light) return t < light_dist;
+    return true;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool hit_back, bool point_light, float light_dist, uint32_t* stack,
+                                          Counters* cnt) {
+    for (uint32_t i = 0; i < sc.n_list; i++) {
+        if (COUNT) cnt->prims++;
+        if (occludes(sc.list[3 * i], sc.list[3 * i + 1], sc.list[3 * i + 2], o, d, hit_back, point_light, light_dist)) return true;
+    }
+    uint32_t cur = sc.root_ref;
+    if (cur == REF_EMPTY) return false;
+    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float tlim = point_light ? prune_limit(light_dist) : INF;
+    uint32_t sp = 0;
+    for (;;) {
+        if (!(cur & REF_LEAF)) {
+            const float4* n = sc.nodes + 4 * (size_t)cur;
+            const float4 lo0 = n[0], hi0 = n[1], lo1 = n[2], hi1 = n[3];
+            float t0, t1;
+            bool h0 = slab(lo0, hi0, o, inv, tlim, &t0);
+            bool h1 = slab(lo1, hi1, o, inv, tlim, &t1);
+            if (COUNT) cnt->nodes += 2;
+            uint32_t r0 = __float_as_uint(lo0.w), r1 = __float_as_uint(lo1.w);
+            if (h0 && h1) { stack[sp * 64] = r1; sp++; cur = r0; }
+            else if (h0) cur = r0;
+            else if (h1) cur = r1;
+            else { if (sp == 0) return false; sp--; cur = stack[sp * 64]; }
+        } else {
+            uint32_t first = (cur & ~REF_LEAF) >> 3, count = (cur & 7u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                const float4* p = sc.tree + 3 * (size_t)(first + k);
+                if (COUNT) cnt->prims++;
+                if (occludes(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
+            }
+            if (sp == 0) return false; sp--; cur = stack[sp * 64];
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t quantise(V3 c) {                                             // raytracer.rs:85-91
+    uint32_t r = (uint32_t)roundf(fminf(fmaxf(c.x, 0.0f), 1.0f) * 255.0f);
+    uint32_t g = (uint32_t)roundf(fminf(fmaxf(c.y, 0.0f), 1.0f) * 255.0f);
+    uint32_t b = (uint32_t)roundf(fminf(fmaxf(c.z, 0.0f), 1.0f) * 255.0f);
+    return (255u << 24) | (r << 16) | (g << 8) | b;
+}
+
+}  // namespace
+
+// Local row r of a shard -> row of the frame.  Tile t (tile_rows rows) belongs to shard t % nshards.
+__device__ __forceinline__ uint32_t frame_row(const DevFrame& f, uint32_t r) {
+    uint32_t lt = r / f.tile_rows, within = r - lt * f.tile_rows;
+    return (lt * f.nshards + f.shard) * f.tile_rows + within;
+}
+
+template <int STACK, bool COUNT>
+__global__ __launch_bounds__(64) void render_kernel(DevScene sc, DevFrame f, uint32_t* __restrict__ out, float4* __restrict__ fold,
+                                                    unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t s_stack[STACK * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tiles_x = (f.width + 7u) >> 3;
+    const uint32_t tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    const uint32_t x = tile_x * 8u + (lane & 7u), r = tile_y * 8u + (lane >> 3);
+    uint32_t* stack = s_stack + lane;
+    Counters cnt = {0u, 0u, 0u, 0u};
+    const bool live = x < f.width && r < f.local_rows;
+    if (live) {
+        const uint32_t y = frame_row(f, r);
+        const size_t pix = (size_t)r * f.width + x;
+        const size_t npix = (size_t)f.local_rows * f.width;
+
+        // raytracer.rs:61-66
+        float b = (f.ph * (f.h2 - ((float)y + 0.5f))) / f.h2;
+        float a = (f.pw * (((float)x + 0.5f) - f.w2)) / f.w2;
+        V3 right = v3(f.right), up = v3(f.up), cv = v3(f.cv);
+        V3 d = vnormalize(vadd(vadd(vscale(right, a), vscale(up, b)), cv));
+        V3 o = v3(f.pos);
+        const V3 ambient = v3(f.ambient);
+
+        V3 cur = v3(0.0f, 0.0f, 0.0f);   // colour returned by the deepest level
+        uint32_t depth = 0;
+        for (;;) {
+            Best best;
+            closest_hit<COUNT>(sc, o, d, stack, &best, &cnt);
+            if (best.prim == NO_PRIM) { cur = v3(0.0f, 0.0f, 0.0f); break; }                    // raytracer.rs:199-201
+
+            // Rebuild the reference's Intersection for the winner (shape.rs:84-95, 122-132, 178-191).
+            const float4* rec = (best.prim & LIST_FLAG) ? sc.list + 3 * (size_t)(best.prim & ~LIST_FLAG) : sc.tree + 3 * (size_t)best.prim;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            const uint32_t km = __float_as_uint(q0.w), kind = km & 3u, mat = km >> 2;
+            V3 point = vadd(o, vscale(d, best.t));
+            V3 normal; bool back = false;
+            if (kind == KIND_TRIANGLE) {
+                V3 e1 = vsub(v3(q1), v3(q0)), e2 = vsub(v3(q2), v3(q0));
+                normal = vnormalize(vcross(e1, e2));
+                back = vdot(normal, d) > 0.0f;
+            } else if (kind == KIND_SPHERE) {
+                normal = vnormalize(vsub(point, v3(q0)));
+            } else {
+                normal = v3(q2);
+            }
+            const float4 m0 = sc.mats[2 * (size_t)mat], m1 = sc.mats[2 * (size_t)mat + 1];
+            const V3 diffuse_color = v3(m0), specular_color = v3(m1);
+            const float shininess = m0.w;
+
+            V3 acc = v3(0.0f, 0.0f, 0.0f);
+            const V3 shadow_origin = vadd(point, vscale(normal, 1e-6f));                        // raytracer.rs:133
+            for (uint32_t li = 0; li < sc.n_lights; li++) {                                      // raytracer.rs:126-179
+                const float4 l0 = sc.lights[2 * li], l1 = sc.lights[2 * li + 1];
+                const bool point_light = l0.w == 0.0f;
+                V3 light_dir; float light_dist = 0.0f;
+                if (point_light) {
+                    V3 to_light = vsub(v3(l0), point);
+                    light_dir = vnormalize(to_light);
+                    light_dist = vnorm(to_light);
+                } else {
+                    light_dir = v3(l0);
+                }
+                if (COUNT) cnt.shadow++;
+                if (in_shadow<COUNT>(sc, shadow_origin, light_dir, back, point_light, light_dist, stack, &cnt)) continue;
+                float n_dot_l = fmaxf(vdot(normal, light_dir), 0.0f);
+                V3 diffuse = vscale(diffuse_color, n_dot_l);
+                V3 view_dir = vneg(d);
+                V3 half_vector = vnormalize(vadd(light_dir, view_dir));
+                float n_dot_h = fmaxf(vdot(normal, half_vector), 0.0f);
+                float factor;
+                if (shininess == 1.0f) factor = n_dot_h;
+                else if (shininess == 0.0f) factor = n_dot_l > 0.0f ? n_dot_h : 0.0f;
+                else factor = n_dot_l > 0.0f ? powf(n_dot_h, shininess) : 0.0f;
+                V3 specular = vscale(specular_color, factor);
+                acc = vadd(acc, vcmul(vadd(diffuse, specular), v3(l1)));
+            }
+            V3 local = vadd(acc, ambient);                                                       // raytracer.rs:181
+            bool reflective = specular_color.x > 0.0f || specular_color.y > 0.0f || specular_color.z > 0.0f;
+            if (!(reflective && depth + 1u < f.maxdepth)) { cur = local; break; }                // raytracer.rs:187
+            fold[(size_t)depth * npix + pix] = make_float4(local.x, local.y, local.z, __uint_as_float(mat));
+            float k2 = 2.0f * vdot(d, normal);                                                   // raytracer.rs:188-190
+            d = vsub(d, vscale(normal, k2));
+            o = shadow_origin;
+            depth++;
+            if (COUNT) cnt.secondary++;
+        }
+        // Backward fold: final_k = local_k + specular_k (*) final_{k+1}                           raytracer.rs:194-195
+        while (depth > 0) {
+            depth--;
+            const float4 rec = fold[(size_t)depth * npix + pix];
+            const float4 m1 = sc.mats[2 * (size_t)__float_as_uint(rec.w) + 1];
+            cur = vadd(v3(rec), vcmul(v3(m1), cur));
+        }
+        out[pix] = quantise(cur);
+    }
+    if (COUNT) {
+        unsigned long long v[4] = {cnt.nodes, cnt.prims, cnt.shadow, cnt.secondary};
+        for (int k = 0; k < 4; k++) {
+            unsigned long long s = v[k];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0 && s) atomicAdd(&counters[k], s);
+        }
+    }
+}
+
+// Scatters the compact per-shard row buffers back into frame order on the gathering GPU.
+__global__ void assemble_kernel(const uint32_t* __restrict__ gathered, uint32_t stride_rows, uint32_t nshards, uint32_t tile_rows,
+                                uint32_t width, uint32_t height, uint32_t* __restrict__ frame) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)width * height;
+    if (i >= n) return;
+    uint32_t y = (uint32_t)(i / width), x = (uint32_t)(i - (size_t)y * width);
+    uint32_t tile = y / tile_rows, within = y - tile * tile_rows;
+    uint32_t shard = tile % nshards, local_tile = tile / nshards;
+    size_t src = ((size_t)shard * stride_rows + (size_t)local_tile * tile_rows + within) * width + x;
+    frame[i] = gathered[src];
+}
+
+// ------------------------------------------------------------------ launchers (called from rt_api.cpp)
+extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, uint32_t* d_out, float4* d_fold,
+                                        unsigned long long* d_counters, int stack_depth, int count, hipStream_t stream) {
+    uint32_t tiles_x = (f->width + 7u) >> 3, tiles_y = (f->local_rows + 7u) >> 3;
+    uint64_t blocks = (uint64_t)tiles_x * tiles_y;
+    if (blocks == 0) return hipSuccess;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((uint32_t)blocks), block(64);
+    if (stack_depth <= 32) {
+        if (count) hipLaunchKernelGGL((render_kernel<32, true>), grid, block, 0, stream, *sc, *f, d_out, d_fold, d_counters);
+        else hipLaunchKernelGGL((render_kernel<32, false>), grid, block, 0, stream, *sc, *f, d_out, d_fold, d_counters);
+    } else {
+        if (count) hipLaunchKernelGGL((render_kernel<64, true>), grid, block, 0, stream, *sc, *f, d_out, d_fold, d_counters);
+        else hipLaunchKernelGGL((render_kernel<64, false>), grid, block, 0, stream, *sc, *f, d_out, d_fold, d_counters);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rtk_launch_assemble(const uint32_t* d_gathered, uint32_t stride_rows, uint32_t nshards, uint32_t tile_rows,
+                                          uint32_t width, uint32_t height, uint32_t* d_frame, hipStream_t stream) {
+    size_t n = (size_t)width * height;
+    if (n == 0) return hipSuccess;
+    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(assemble_kernel, dim3(blocks), dim3(256), 0, stream, d_gathered, stride_rows, nshards, tile_rows, width, height, d_frame);
+    return hipGetLastError();
+}

@@ -1,0 +1,300 @@
+// rt_api.cpp -- implementation of the C ABI declared in include/rt_amd.h.
+//
+// One process drives one GPU.  The scene lives in one device blob (layout.h) between
+// rt_upload_scene / rt_adopt_scene_blob and rt_shutdown; work buffers (frame, per-depth fold
+// records, counters) grow on demand and are reused across calls.  There is no CPU fallback:
+// every entry point that needs the GPU fails with an error when HIP does.
+#include "../../include/rt_amd.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+#include "errors.h"
+#include "layout.h"
+#include "scene_pack.h"
+
+namespace {
+
+struct State {
+    bool inited = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* d_blob = nullptr; size_t blob_bytes = 0; bool blob_owned = false; bool have_scene = false;
+    rtl::BlobHeader hdr{};
+    DevScene dsc{};
+    rt_bvh_info info{};
+    uint32_t* d_out = nullptr; size_t out_cap = 0;          // pixels
+    float4* d_fold = nullptr; size_t fold_cap = 0;          // records
+    unsigned long long* d_counters = nullptr;               // nodes, prims, shadow, secondary
+};
+State g;
+
+int fail(const std::string& m) { rte::set_error(m); return 1; }
+int fail_hip(const char* what, hipError_t e) { rte::set_error(std::string(what) + ": " + hipGetErrorString(e)); return 1; }
+
+#define HIP_TRY(expr)                                                  \
+    do {                                                               \
+        hipError_t e_ = (expr);                                        \
+        if (e_ != hipSuccess) return fail_hip(#expr, e_);              \
+    } while (0)
+
+void release_scene() {
+    if (g.d_blob && g.blob_owned) (void)hipFree(g.d_blob);
+    g.d_blob = nullptr; g.blob_bytes = 0; g.blob_owned = false; g.have_scene = false;
+}
+
+void point_at_blob(void* d_blob, const rtl::BlobHeader& h) {
+    const char* base = (const char*)d_blob;
+    g.hdr = h;
+    g.dsc.nodes = (const float4*)(base + h.off_nodes);
+    g.dsc.tree = (const float4*)(base + h.off_tree_shapes);
+    g.dsc.list = (const float4*)(base + h.off_list_shapes);
+    g.dsc.mats = (const float4*)(base + h.off_materials);
+    g.dsc.lights = (const float4*)(base + h.off_lights);
+    g.dsc.n_list = h.n_list_shapes; g.dsc.n_lights = h.n_lights; g.dsc.root_ref = h.root_ref; g.dsc.pad = 0;
+    g.info.node_pairs = h.n_pairs; g.info.leaves = h.n_leaves; g.info.max_depth = h.max_depth; g.info.max_leaf = h.max_leaf;
+    g.info.bvh_prims = h.n_tree_shapes; g.info.list_prims = h.n_list_shapes; g.info.sah_cost = h.sah_cost;
+    g.have_scene = true;
+}
+
+int check_frame(const rt_frame* f) {
+    if (!f) return fail("rt_frame is NULL");
+    if (f->width == 0 || f->height == 0) return fail("Width and height must be greater than zero");
+    if ((uint64_t)f->width * f->height > (1ull << 31)) return fail("frame larger than 2^31 pixels");
+    return 0;
+}
+
+int ensure_fold(size_t records) {
+    if (records <= g.fold_cap) return 0;
+    if (records * sizeof(float4) > (200ull << 30)) return fail("maxdepth x pixels needs more than 200 GiB of fold records");
+    if (g.d_fold) { (void)hipFree(g.d_fold); g.d_fold = nullptr; g.fold_cap = 0; }
+    HIP_TRY(hipMalloc((void**)&g.d_fold, records * sizeof(float4)));
+    g.fold_cap = records;
+    return 0;
+}
+
+// Launches the render kernel for one shard into d_out (device).  With stats != NULL the call
+// is timed with HIP events on the library's stream and waits for completion.
+int render_shard(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32_t tile_rows, uint32_t* d_out, rt_stats* stats, int count_work) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (!g.inited) return fail("rt_init has not been called");
+    if (!g.have_scene) return fail("no scene uploaded");
+    if (check_frame(frame)) return 1;
+    if (nshards == 0 || shard >= nshards || tile_rows == 0) return fail("bad shard description");
+    uint32_t local_rows = rt_shard_rows(frame->height, shard, nshards, tile_rows);
+    DevFrame f{};
+    std::memcpy(f.pos, frame->pos, sizeof(f.pos)); std::memcpy(f.cv, frame->cv, sizeof(f.cv));
+    std::memcpy(f.right, frame->right, sizeof(f.right)); std::memcpy(f.up, frame->up, sizeof(f.up));
+    f.pw = frame->pixel_w; f.ph = frame->pixel_h; f.w2 = frame->half_w; f.h2 = frame->half_h;
+    f.width = frame->width; f.height = frame->height; f.maxdepth = frame->maxdepth;
+    std::memcpy(f.ambient, frame->ambient, sizeof(f.ambient));
+    f.shard = shard; f.nshards = nshards; f.tile_rows = tile_rows; f.local_rows = local_rows;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (local_rows == 0) return 0;
+    if (!d_out) return fail("output buffer is NULL");
+    size_t npix = (size_t)local_rows * frame->width;
+    uint32_t levels = frame->maxdepth > 1 ? frame->maxdepth - 1 : 0;
+    if (ensure_fold(npix * (size_t)levels)) return 1;
+    if (count_work) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 4 * sizeof(unsigned long long), g.stream));
+    if (stats) HIP_TRY(hipEventRecord(g.ev0, g.stream));
+    HIP_TRY(rtk_launch_render(&g.dsc, &f, d_out, g.d_fold, g.d_counters, (int)g.hdr.max_depth, count_work, g.stream));
+    if (stats) {
+        HIP_TRY(hipEventRecord(g.ev1, g.stream));
+        HIP_TRY(hipEventSynchronize(g.ev1));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+        stats->kernel_ms = ms;
+        stats->primary = npix;
+        if (count_work) {
+            unsigned long long c[4];
+            HIP_TRY(hipMemcpy(c, g.d_counters, sizeof(c), hipMemcpyDeviceToHost));
+            stats->nodes_visited = c[0]; stats->prims_tested = c[1]; stats->shadow = c[2]; stats->secondary = c[3];
+        }
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return rte::last_error(); }
+
+int rt_frame_from_camera(const float position[3], const float look_at[3], const float up[3], float fov_degrees, uint32_t width,
+                         uint32_t height, uint32_t maxdepth, const float ambient[3], rt_frame* out) {
+    if (!position || !look_at || !up || !ambient || !out) return fail("rt_frame_from_camera: NULL argument");
+    if (width == 0 || height == 0) return fail("Width and height must be greater than zero");
+    // Strict binary32 in the reference's order (raytracer.rs:46-55, camera.rs:11-13).
+    struct V { float x, y, z; };
+    auto sub = [](V a, V b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; };
+    auto dot = [](V a, V b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; };
+    auto cross = [](V a, V b) { return V{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+    auto normalize = [&](V a) { float inv = 1.0f / sqrtf(dot(a, a)); return V{a.x * inv, a.y * inv, a.z * inv}; };
+    V pos{position[0], position[1], position[2]}, look{look_at[0], look_at[1], look_at[2]}, upv{up[0], up[1], up[2]};
+    V cv = normalize(normalize(sub(look, pos)));
+    V right = normalize(cross(cv, upv));
+    V v = normalize(cross(right, cv));
+    const float PI_F = 3.14159265358979323846f;
+    float fovrad = fov_degrees * PI_F / 180.0f;
+    float ph = tanf(fovrad / 2.0f);
+    float pw = ph * ((float)width / (float)height);
+    out->pos[0] = pos.x; out->pos[1] = pos.y; out->pos[2] = pos.z;
+    out->cv[0] = cv.x; out->cv[1] = cv.y; out->cv[2] = cv.z;
+    out->right[0] = right.x; out->right[1] = right.y; out->right[2] = right.z;
+    out->up[0] = v.x; out->up[1] = v.y; out->up[2] = v.z;
+    out->pixel_w = pw; out->pixel_h = ph;
+    out->half_w = (float)width / 2.0f; out->half_h = (float)height / 2.0f;
+    out->width = width; out->height = height; out->maxdepth = maxdepth;
+    out->ambient[0] = ambient[0]; out->ambient[1] = ambient[1]; out->ambient[2] = ambient[2];
+    return 0;
+}
+
+int rt_init(int device) {
+    if (g.inited) {
+        if (g.device == device) return 0;
+        return fail("rt_init: already bound to another device; call rt_shutdown first");
+    }
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail("rt_init: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&g.ev0));
+    HIP_TRY(hipEventCreate(&g.ev1));
+    HIP_TRY(hipMalloc((void**)&g.d_counters, 4 * sizeof(unsigned long long)));
+    g.device = device; g.inited = true;
+    return 0;
+}
+
+int rt_upload_scene(const rt_scene* scene) {
+    if (!g.inited) return fail("rt_init has not been called");
+    if (!scene) return fail("rt_scene is NULL");
+    std::vector<uint8_t> blob; rt_bvh_info info{}; std::string err;
+    if (!rtp::pack_scene(*scene, &blob, &info, &err)) return fail(err);
+    rtl::BlobHeader h; std::memcpy(&h, blob.data(), sizeof(h));
+    if (!rtp::validate_header(h, blob.size(), &err)) return fail(err);
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    release_scene();
+    HIP_TRY(hipMalloc(&g.d_blob, blob.size()));
+    g.blob_owned = true; g.blob_bytes = blob.size();
+    HIP_TRY(hipMemcpyAsync(g.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    point_at_blob(g.d_blob, h);
+    g.info = info;
+    return 0;
+}
+
+int rt_get_bvh_info(rt_bvh_info* out) {
+    if (!g.have_scene) return fail("no scene uploaded");
+    if (!out) return fail("rt_bvh_info is NULL");
+    *out = g.info;
+    return 0;
+}
+
+int rt_scene_blob(void** device_ptr, size_t* bytes) {
+    if (!g.have_scene) return fail("no scene uploaded");
+    if (!device_ptr || !bytes) return fail("rt_scene_blob: NULL argument");
+    *device_ptr = g.d_blob; *bytes = g.blob_bytes;
+    return 0;
+}
+
+int rt_adopt_scene_blob(void* device_ptr, size_t bytes) {
+    if (!g.inited) return fail("rt_init has not been called");
+    if (!device_ptr || bytes < sizeof(rtl::BlobHeader)) return fail("rt_adopt_scene_blob: buffer too small");
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    rtl::BlobHeader h;
+    HIP_TRY(hipMemcpy(&h, device_ptr, sizeof(h), hipMemcpyDeviceToHost));
+    std::string err;
+    if (!rtp::validate_header(h, bytes, &err)) return fail(err);
+    release_scene();
+    g.d_blob = device_ptr; g.blob_bytes = bytes; g.blob_owned = false;
+    point_at_blob(device_ptr, h);
+    g.info.build_ms = 0.0;
+    return 0;
+}
+
+uint32_t rt_shard_rows(uint32_t height, uint32_t shard, uint32_t nshards, uint32_t tile_rows) {
+    if (nshards == 0 || tile_rows == 0 || shard >= nshards) return 0;
+    uint64_t rows = 0;
+    uint32_t ntiles = (height + tile_rows - 1) / tile_rows;
+    for (uint32_t t = shard; t < ntiles; t += nshards) {
+        uint32_t r0 = t * tile_rows, r1 = r0 + tile_rows;
+        if (r1 > height) r1 = height;
+        rows += r1 - r0;
+    }
+    return (uint32_t)rows;
+}
+
+int rt_render_tiles(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32_t tile_rows, uint32_t* d_out, rt_stats* stats,
+                    int count_work) {
+    if (g.inited) HIP_TRY(hipSetDevice(g.device));
+    return render_shard(frame, shard, nshards, tile_rows, d_out, stats, count_work);
+}
+
+int rt_render(const rt_frame* frame, uint32_t* out_pixels, rt_stats* stats, int count_work) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (!g.inited) return fail("rt_init has not been called");
+    if (check_frame(frame)) return 1;
+    if (!out_pixels) return fail("output buffer is NULL");
+    HIP_TRY(hipSetDevice(g.device));
+    size_t npix = (size_t)frame->width * frame->height;
+    if (npix > g.out_cap) {
+        if (g.d_out) { (void)hipFree(g.d_out); g.d_out = nullptr; g.out_cap = 0; }
+        HIP_TRY(hipMalloc((void**)&g.d_out, npix * sizeof(uint32_t)));
+        g.out_cap = npix;
+    }
+    rt_stats local{};
+    if (render_shard(frame, 0, 1, 8, g.d_out, &local, count_work)) return 1;
+    HIP_TRY(hipMemcpyAsync(out_pixels, g.d_out, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (stats) {
+        *stats = local;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+}
+
+int rt_assemble_tiles(const uint32_t* d_gathered, uint32_t rows_per_shard_stride, uint32_t nshards, uint32_t tile_rows, uint32_t width,
+                      uint32_t height, uint32_t* d_frame) {
+    if (!g.inited) return fail("rt_init has not been called");
+    if (!d_gathered || !d_frame) return fail("rt_assemble_tiles: NULL buffer");
+    if (nshards == 0 || tile_rows == 0 || width == 0 || height == 0) return fail("rt_assemble_tiles: bad geometry");
+    for (uint32_t s = 0; s < nshards; s++)
+        if (rt_shard_rows(height, s, nshards, tile_rows) > rows_per_shard_stride) return fail("rt_assemble_tiles: stride smaller than a shard");
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(rtk_launch_assemble(d_gathered, rows_per_shard_stride, nshards, tile_rows, width, height, d_frame, g.stream));
+    return 0;
+}
+
+void* rt_stream(void) { return (void*)g.stream; }
+
+int rt_synchronize(void) {
+    if (!g.inited) return fail("rt_init has not been called");
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+void rt_shutdown(void) {
+    if (!g.inited) return;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    release_scene();
+    if (g.d_out) (void)hipFree(g.d_out);
+    if (g.d_fold) (void)hipFree(g.d_fold);
+    if (g.d_counters) (void)hipFree(g.d_counters);
+    if (g.ev0) (void)hipEventDestroy(g.ev0);
+    if (g.ev1) (void)hipEventDestroy(g.ev1);
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    g = State();
+}
+
+}  // extern "C"

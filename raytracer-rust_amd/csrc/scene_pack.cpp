@@ -1,0 +1,193 @@
+// scene_pack.cpp -- flattened scene (rt_scene) -> device blob (layout.h).
+//
+// Host half of RayTracer::new (reference src/raytracer/raytracer.rs:29-38): computes the
+// shape boxes the way shape.rs:205-234 does, builds the tree (bvh_build.cpp) and writes
+// node pairs, reordered shape records, the material table and the lights into one buffer.
+#include "scene_pack.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+
+#include "bvh_build.h"
+
+namespace rtp {
+
+namespace {
+
+struct MatKey {
+    uint32_t w[7];
+    bool operator==(const MatKey& o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
+};
+struct MatHash {
+    size_t operator()(const MatKey& k) const {
+        uint64_t h = 1469598103934665603ull;
+        for (int i = 0; i < 7; i++) { h ^= k.w[i]; h *= 1099511628211ull; }
+        return (size_t)h;
+    }
+};
+
+struct Flat {              // one shape in file order
+    uint32_t kind, idx_in_kind, order, mat;
+};
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+void fill_record(const rt_scene& s, const Flat& f, rtl::ShapeRec* r) {
+    std::memset(r, 0, sizeof(*r));
+    r->kind_mat = f.kind | (f.mat << 2);
+    r->order = f.order;
+    size_t i = f.idx_in_kind;
+    if (f.kind == rtl::KIND_TRIANGLE) {
+        for (int k = 0; k < 3; k++) { r->q0[k] = s.tri_v0[3 * i + k]; r->q1[k] = s.tri_v1[3 * i + k]; r->q2[k] = s.tri_v2[3 * i + k]; }
+    } else if (f.kind == rtl::KIND_SPHERE) {
+        for (int k = 0; k < 3; k++) r->q0[k] = s.sph_center[3 * i + k];
+        r->q1[0] = s.sph_radius[i];
+    } else {
+        for (int k = 0; k < 3; k++) { r->q0[k] = s.pl_point[3 * i + k]; r->q2[k] = s.pl_normal[3 * i + k]; }
+    }
+}
+
+}  // namespace
+
+bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err) {
+    if (h.magic != rtl::BLOB_MAGIC || h.version != 1) { *err = "scene blob: bad magic or version"; return false; }
+    if (h.total_bytes != bytes) { *err = "scene blob: size does not match its header"; return false; }
+    auto fits = [&](uint64_t off, uint64_t n, uint64_t each) { return off % 16 == 0 && off >= sizeof(rtl::BlobHeader) && off + n * each <= bytes; };
+    if (!fits(h.off_nodes, h.n_pairs, sizeof(rtl::NodePair)) || !fits(h.off_tree_shapes, h.n_tree_shapes, sizeof(rtl::ShapeRec)) ||
+        !fits(h.off_list_shapes, h.n_list_shapes, sizeof(rtl::ShapeRec)) || !fits(h.off_materials, h.n_materials, sizeof(rtl::MaterialRec)) ||
+        !fits(h.off_lights, h.n_lights, sizeof(rtl::LightRec))) {
+        *err = "scene blob: section outside the buffer";
+        return false;
+    }
+    if (h.max_depth > TREE_DEPTH_LIMIT) { *err = "scene blob: tree deeper than the traversal stack"; return false; }
+    if (h.root_ref != rtl::REF_EMPTY) {
+        if (h.root_ref & rtl::REF_LEAF) {
+            uint32_t first = (h.root_ref & ~rtl::REF_LEAF) >> 3, cnt = (h.root_ref & 7u) + 1u;
+            if ((uint64_t)first + cnt > h.n_tree_shapes) { *err = "scene blob: root leaf outside the shape array"; return false; }
+        } else if (h.root_ref >= h.n_pairs) { *err = "scene blob: root outside the node array"; return false; }
+    }
+    return true;
+}
+
+bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info, std::string* err) {
+    auto t0 = std::chrono::steady_clock::now();
+    if ((s.ntri && (!s.tri_v0 || !s.tri_v1 || !s.tri_v2 || !s.tri_mat)) || (s.nsph && (!s.sph_center || !s.sph_radius || !s.sph_mat)) ||
+        (s.npl && (!s.pl_point || !s.pl_normal || !s.pl_mat)) || (s.nlights && !s.lights)) {
+        *err = "rt_scene: a non-empty array is NULL";
+        return false;
+    }
+    uint64_t total = (uint64_t)s.ntri + s.nsph + s.npl;
+    if (total > rtl::MAX_TREE_SHAPES) { *err = "rt_scene: too many shapes"; return false; }
+
+    // File order of every shape (ties on exactly equal distance go to the earlier shape).
+    std::vector<Flat> flat; flat.reserve(total);
+    for (uint32_t i = 0; i < s.ntri; i++) flat.push_back({rtl::KIND_TRIANGLE, i, s.tri_order ? s.tri_order[i] : i, 0});
+    for (uint32_t i = 0; i < s.nsph; i++) flat.push_back({rtl::KIND_SPHERE, i, s.sph_order ? s.sph_order[i] : s.ntri + i, 0});
+    for (uint32_t i = 0; i < s.npl; i++) flat.push_back({rtl::KIND_PLANE, i, s.pl_order ? s.pl_order[i] : s.ntri + s.nsph + i, 0});
+
+    // Material table: shapes copy the parser's current material (config_builder.rs:401-403), so
+    // a scene has few distinct ones.
+    std::unordered_map<MatKey, uint32_t, MatHash> mat_ids;
+    std::vector<rtl::MaterialRec> mats;
+    for (Flat& f : flat) {
+        const float* m = f.kind == rtl::KIND_TRIANGLE ? s.tri_mat + 7 * (size_t)f.idx_in_kind
+                       : f.kind == rtl::KIND_SPHERE ? s.sph_mat + 7 * (size_t)f.idx_in_kind : s.pl_mat + 7 * (size_t)f.idx_in_kind;
+        MatKey k; std::memcpy(k.w, m, sizeof(k.w));
+        auto it = mat_ids.find(k);
+        if (it == mat_ids.end()) {
+            rtl::MaterialRec r{};
+            r.diffuse[0] = m[0]; r.diffuse[1] = m[1]; r.diffuse[2] = m[2]; r.specular[0] = m[3]; r.specular[1] = m[4]; r.specular[2] = m[5];
+            r.shininess = m[6];
+            it = mat_ids.emplace(k, (uint32_t)mats.size()).first;
+            mats.push_back(r);
+            if (mats.size() >= (1u << 30)) { *err = "rt_scene: too many distinct materials"; return false; }
+        }
+        f.mat = it->second;
+    }
+
+    // Split into always-tested shapes and tree shapes.
+    uint32_t bounded = s.ntri + s.nsph;
+    bool use_tree = bounded > SMALL_SCENE;
+    std::vector<Flat> list_shapes, tree_in;
+    for (const Flat& f : flat) {
+        if (f.kind == rtl::KIND_PLANE || !use_tree) list_shapes.push_back(f); else tree_in.push_back(f);
+    }
+    std::sort(list_shapes.begin(), list_shapes.end(), [](const Flat& a, const Flat& b) { return a.order < b.order; });
+
+    // Boxes of the tree shapes (shape.rs:208-234).
+    size_t nt = tree_in.size();
+    std::vector<float> lo(3 * nt), hi(3 * nt);
+    for (size_t j = 0; j < nt; j++) {
+        const Flat& f = tree_in[j]; size_t i = f.idx_in_kind;
+        for (int k = 0; k < 3; k++) {
+            if (f.kind == rtl::KIND_SPHERE) {
+                lo[3 * j + k] = s.sph_center[3 * i + k] - s.sph_radius[i];
+                hi[3 * j + k] = s.sph_center[3 * i + k] + s.sph_radius[i];
+            } else {
+                float a = s.tri_v0[3 * i + k], b = s.tri_v1[3 * i + k], c = s.tri_v2[3 * i + k];
+                lo[3 * j + k] = std::min(std::min(a, b), c);
+                hi[3 * j + k] = std::max(std::max(a, b), c);
+            }
+            if (!std::isfinite(lo[3 * j + k]) || !std::isfinite(hi[3 * j + k])) { *err = "rt_scene: non-finite shape coordinates"; return false; }
+        }
+    }
+    // Absolute padding: a few parts per million of the extent that holds the bulk of the shapes
+    // (5th..95th percentile of the box centres, so one huge ground sphere does not set the scale).
+    float pad_abs = 0.0f;
+    if (nt > 0) {
+        float extent = 0.0f;
+        std::vector<float> c(nt);
+        for (int k = 0; k < 3; k++) {
+            for (size_t j = 0; j < nt; j++) c[j] = 0.5f * lo[3 * j + k] + 0.5f * hi[3 * j + k];
+            size_t a = nt / 20, b = nt - 1 - nt / 20;
+            std::nth_element(c.begin(), c.begin() + a, c.end()); float p5 = c[a];
+            std::nth_element(c.begin(), c.begin() + b, c.end()); float p95 = c[b];
+            extent = std::max(extent, p95 - p5);
+        }
+        pad_abs = extent * 4e-6f;
+    }
+
+    rtb::BvhResult bvh;
+    if (!rtb::build_bvh(lo.data(), hi.data(), (uint32_t)nt, TREE_DEPTH_LIMIT, pad_abs, &bvh, err)) return false;
+
+    // Assemble the blob.
+    rtl::BlobHeader h{};
+    h.magic = rtl::BLOB_MAGIC; h.version = 1;
+    h.n_pairs = (uint32_t)bvh.pairs.size(); h.n_tree_shapes = (uint32_t)nt; h.n_list_shapes = (uint32_t)list_shapes.size();
+    h.n_materials = (uint32_t)mats.size(); h.n_lights = s.nlights;
+    h.root_ref = bvh.root_ref; h.max_depth = bvh.max_depth; h.max_leaf = bvh.max_leaf; h.n_leaves = bvh.n_leaves; h.sah_cost = (float)bvh.sah_cost;
+    size_t off = sizeof(rtl::BlobHeader);
+    h.off_nodes = off; off = align256(off + (size_t)h.n_pairs * sizeof(rtl::NodePair));
+    h.off_tree_shapes = off; off = align256(off + nt * sizeof(rtl::ShapeRec));
+    h.off_list_shapes = off; off = align256(off + list_shapes.size() * sizeof(rtl::ShapeRec));
+    h.off_materials = off; off = align256(off + mats.size() * sizeof(rtl::MaterialRec));
+    h.off_lights = off; off = align256(off + (size_t)s.nlights * sizeof(rtl::LightRec));
+    h.total_bytes = off;
+    blob->assign(off, 0);
+    std::memcpy(blob->data(), &h, sizeof(h));
+    if (h.n_pairs) std::memcpy(blob->data() + h.off_nodes, bvh.pairs.data(), (size_t)h.n_pairs * sizeof(rtl::NodePair));
+    rtl::ShapeRec* ts = (rtl::ShapeRec*)(blob->data() + h.off_tree_shapes);
+#pragma omp parallel for schedule(static) if (nt > 100000)
+    for (int64_t j = 0; j < (int64_t)nt; j++) fill_record(s, tree_in[bvh.order[j]], &ts[j]);
+    rtl::ShapeRec* ls = (rtl::ShapeRec*)(blob->data() + h.off_list_shapes);
+    for (size_t j = 0; j < list_shapes.size(); j++) fill_record(s, list_shapes[j], &ls[j]);
+    if (!mats.empty()) std::memcpy(blob->data() + h.off_materials, mats.data(), mats.size() * sizeof(rtl::MaterialRec));
+    rtl::LightRec* lr = (rtl::LightRec*)(blob->data() + h.off_lights);
+    for (uint32_t i = 0; i < s.nlights; i++) {
+        const float* l = s.lights + 7 * (size_t)i;
+        if (!(l[0] == 0.0f || l[0] == 1.0f)) { *err = "rt_scene: light kind must be 0 (point) or 1 (directional)"; return false; }
+        lr[i].kind = l[0]; lr[i].v[0] = l[1]; lr[i].v[1] = l[2]; lr[i].v[2] = l[3];
+        lr[i].color[0] = l[4]; lr[i].color[1] = l[5]; lr[i].color[2] = l[6]; lr[i].pad = 0.0f;
+    }
+    if (info) {
+        info->node_pairs = h.n_pairs; info->leaves = h.n_leaves; info->max_depth = h.max_depth; info->max_leaf = h.max_leaf;
+        info->bvh_prims = h.n_tree_shapes; info->list_prims = h.n_list_shapes; info->sah_cost = bvh.sah_cost;
+        info->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return true;
+}
+
+}  // namespace rtp

@@ -1,0 +1,27 @@
+// scene_pack.h -- turns the flattened scene of the C ABI into the device blob of layout.h.
+#ifndef RT_SCENE_PACK_H
+#define RT_SCENE_PACK_H
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "layout.h"
+
+namespace rtp {
+
+// Scenes with at most this many bounded shapes skip the tree: every shape is tested for
+// every ray, straight from the list (the jalon3/5/6 scenes have at most 6).
+constexpr uint32_t SMALL_SCENE = 8;
+
+// Longest root-to-leaf path the builder may produce = deepest traversal stack a kernel offers.
+constexpr uint32_t TREE_DEPTH_LIMIT = 64;
+
+bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info, std::string* err);
+
+// Checks a blob header copied back from the device before the kernels are pointed at it.
+bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err);
+
+}  // namespace rtp
+#endif

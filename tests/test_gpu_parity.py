@@ -1,0 +1,220 @@
+"""GPU parity: the HIP render path, called through the C ABI, against the CPU oracle, the
+reference's golden images and size-independent properties.
+
+Tolerance (the render is binary32 on both sides, the only freedom is powf): at least 99.9 % of
+the pixels identical after 8-bit quantisation and no channel off by more than 2/255.  Where the
+reference holds a golden image its own criterion is applied too: Image::compare must count zero
+pixels (src/raytracer/raytracer.rs:369).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import oracle as O
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+rt = ge.load_package()
+
+MIN_IDENTICAL = 0.999
+MAX_CHANNEL_DIFF = 2
+
+SCENES = sorted(glob.glob(os.path.join(GOLDEN, "test_file", "*", "*.test")))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    rt.init(0)
+    yield
+
+
+def _assert_parity(got, want, min_identical=MIN_IDENTICAL):
+    c, _ = O.compare(got, want)
+    assert c["identical_frac"] >= min_identical and c["max_diff"] <= MAX_CHANNEL_DIFF, c
+    return c
+
+
+@pytest.mark.parametrize("scene", SCENES, ids=[os.path.basename(s)[:-5] for s in SCENES])
+def test_reference_test_scenes(scene):
+    cfg = rt.ParsedConfigState().load_config_file(scene)
+    tracer = rt.RayTracer.new(cfg)
+    img = tracer.render(count_work=True)
+    want, st = O.OracleScene.load(scene).render(mode=O.OracleScene.MODE_ALL)
+    c = _assert_parity(img.pixels(), want)
+    # these scenes have no tree: nothing is culled, so the match should be exact up to powf
+    assert c["identical_frac"] >= 0.99999, c
+    # the reference's own pass criterion against its golden image
+    diff, _ = rt.Image.compare(img, rt.file_to_image(scene[:-5] + ".png"))
+    assert diff == 0
+    # ray accounting equals the oracle's
+    got = tracer.last_stats
+    assert (got["primary"], got["shadow"], got["secondary"]) == (st["primary"], st["shadow"], st["secondary"])
+
+
+def test_dragon_native_size_against_reference_render():
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
+    tracer = rt.RayTracer.new(cfg)
+    img = tracer.render(count_work=True)
+    gold = rt.file_to_image(os.path.join(GOLDEN, "dragon3.png"))      # the reference's own output of this scene
+    c = _assert_parity(img.pixels(), gold.pixels())
+    diff, _ = rt.Image.compare(img, gold)
+    assert diff == 0
+    st = tracer.last_stats
+    assert (st["primary"], st["shadow"], st["secondary"]) == (307200, 1098150, 532878)
+    print("dragon 640x480 vs dragon3.png:", c, st)
+
+
+def test_dragon_4k_against_oracle():
+    path = os.path.join(GOLDEN, "final_avec_bonus.scene")
+    cfg = rt.ParsedConfigState().load_config_file(path)
+    cfg.set_size(3840, 2160)
+    tracer = rt.RayTracer.new(cfg)
+    img = tracer.render()
+    want, st = O.OracleScene.load(path).render(width=3840, height=2160, mode=O.OracleScene.MODE_TREE_PRUNED)
+    c = _assert_parity(img.pixels(), want)
+    print("dragon 3840x2160 vs oracle:", c, "kernel ms", tracer.last_stats["kernel_ms"])
+
+
+def test_test_scene_full_size_against_oracle():
+    path = os.path.join(GOLDEN, "test.scene")
+    cfg = rt.ParsedConfigState().load_config_file(path)
+    tracer = rt.RayTracer.new(cfg)
+    img = tracer.render(count_work=True)
+    want, st = O.OracleScene.load(path).render(mode=O.OracleScene.MODE_TREE_PRUNED)
+    c = _assert_parity(img.pixels(), want)
+    got = tracer.last_stats
+    assert (got["primary"], got["shadow"], got["secondary"]) == (st["primary"], st["shadow"], st["secondary"]) == (2073600, 2073600, 0)
+    print("test.scene 1920x1080 vs oracle:", c)
+
+
+def _random_scene(rng, ntri, nsph, npl, nlights, maxdepth, size=(96, 64)):
+    lines = [f"size {size[0]} {size[1]}", "camera 0 1 9 0 0 0 0 1 0 50", "ambient .05 .05 .05", f"maxdepth {maxdepth}"]
+    for _ in range(nlights):
+        p = rng.uniform(-8, 8, 3)
+        col = rng.uniform(.2, .6, 3)
+        kind = "point" if rng.random() < .6 else "directional"
+        lines.append(f"{kind} {p[0]:.4f} {abs(p[1]) + 3:.4f} {p[2] + 8:.4f} {col[0]:.3f} {col[1]:.3f} {col[2]:.3f}")
+    nv = 3 * ntri
+    lines.append(f"maxverts {nv}")
+
+    def material():
+        d, s = rng.uniform(0, .9, 3), rng.uniform(0, .6, 3) * (rng.random() < .7)
+        sh = rng.choice([0, 1, 5, 20, 77.5])
+        return [f"diffuse {d[0]:.3f} {d[1]:.3f} {d[2]:.3f}", f"specular {s[0]:.3f} {s[1]:.3f} {s[2]:.3f}", f"shininess {sh}"]
+
+    for i in range(ntri):
+        c = rng.uniform(-4, 4, 3)
+        for _ in range(3):
+            v = c + rng.uniform(-1.2, 1.2, 3)
+            lines.append(f"vertex {v[0]:.5f} {v[1]:.5f} {v[2]:.5f}")
+    for i in range(ntri):
+        if i % 7 == 0:
+            lines += material()
+        lines.append(f"tri {3 * i} {3 * i + 1} {3 * i + 2}")
+    for i in range(nsph):
+        if i % 3 == 0:
+            lines += material()
+        c = rng.uniform(-4, 4, 3)
+        lines.append(f"sphere {c[0]:.4f} {c[1]:.4f} {c[2]:.4f} {rng.uniform(.2, 1.2):.4f}")
+    for i in range(npl):
+        lines += material()
+        lines.append(f"plane 0 {-4 - i} 0 {rng.uniform(-.2, .2):.3f} 1 {rng.uniform(-.2, .2):.3f}")
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed,ntri,nsph,npl,nlights,maxdepth", [
+    (1, 0, 0, 0, 1, 1),          # empty scene: black frame
+    (2, 40, 10, 1, 2, 4),
+    (3, 300, 60, 2, 3, 6),       # tree with mixed shapes, two planes in the always-tested list
+    (4, 9, 0, 0, 0, 3),          # just above the small-scene threshold, no lights
+    (5, 0, 200, 0, 2, 10),
+    (6, 2000, 0, 1, 1, 5),
+])
+def test_random_scenes_against_exhaustive_oracle(seed, ntri, nsph, npl, nlights, maxdepth):
+    text = _random_scene(np.random.default_rng(seed), ntri, nsph, npl, nlights, maxdepth)
+    cfg = rt.ParsedConfigState().parse_text(text)
+    tracer = rt.RayTracer.new(cfg)
+    img = tracer.render(count_work=True)
+    want, st = O.OracleScene.parse(text).render(mode=O.OracleScene.MODE_ALL)
+    c = _assert_parity(img.pixels(), want)
+    got = tracer.last_stats
+    assert (got["primary"], got["shadow"], got["secondary"]) == (st["primary"], st["shadow"], st["secondary"])
+    if ntri + nsph + npl == 0:
+        assert (img.data == 0xFF000000).all()
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 5), (8, 8), (9, 17), (333, 3)])
+def test_ragged_frame_sizes(size):
+    path = os.path.join(GOLDEN, "test_file", "jalon6", "tp64.test")
+    cfg = rt.ParsedConfigState().load_config_file(path)
+    cfg.set_size(*size)
+    img = rt.RayTracer.new(cfg).render()
+    want, _ = O.OracleScene.load(path).render(width=size[0], height=size[1])
+    assert img.pixels().shape == want.shape
+    _assert_parity(img.pixels(), want, min_identical=0.99)
+
+
+def test_render_is_deterministic_and_instrumentation_does_not_change_pixels():
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
+    tracer = rt.RayTracer.new(cfg)
+    a = tracer.render().data.copy()
+    b = tracer.render(count_work=True).data.copy()
+    c = tracer.render().data.copy()
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    st = tracer.last_stats
+
+
+@pytest.mark.parametrize("nshards,tile_rows", [(2, 8), (8, 8), (3, 16), (5, 7)])
+def test_sharded_tiles_reassemble_to_the_full_frame(nshards, tile_rows):
+    import torch
+    path = os.path.join(GOLDEN, "final_avec_bonus.scene")
+    cfg = rt.ParsedConfigState().load_config_file(path)
+    cfg.set_size(400, 301)
+    tracer = rt.RayTracer.new(cfg)
+    full = tracer.render().pixels()
+    frame = cfg.frame()
+    W, H = frame.width, frame.height
+    stride = max(rt.shard_rows(H, s, nshards, tile_rows) for s in range(nshards))
+    gathered = torch.zeros((nshards, stride, W), dtype=torch.int32, device="cuda:0")
+    for s in range(nshards):
+        rt.render_tiles(frame, s, nshards, gathered[s].data_ptr(), tile_rows=tile_rows)
+    out = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+    rt.assemble_tiles(gathered.data_ptr(), stride, nshards, W, H, out.data_ptr(), tile_rows=tile_rows)
+    rt.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, full)
+
+
+def test_scene_blob_round_trip_replicates_the_scene():
+    import torch
+    path = os.path.join(GOLDEN, "test_file", "jalon6", "tp64.test")
+    cfg = rt.ParsedConfigState().load_config_file(path)
+    tracer = rt.RayTracer.new(cfg)
+    a = tracer.render().data.copy()
+    ptr, nbytes = rt.scene_blob()
+    copy = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ctypes.c_void_p(copy.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), 3) == 0
+    rt.adopt_scene_blob(copy.data_ptr(), nbytes)
+    b, _ = rt.render(cfg.frame())
+    assert np.array_equal(a, b.reshape(-1))
+    with pytest.raises(rt.RtError, match="scene blob"):
+        rt.adopt_scene_blob(copy.data_ptr(), nbytes - 256)
+    rt.adopt_scene_blob(copy.data_ptr(), nbytes)      # leave a valid scene behind
+
+
+def test_errors_are_reported_not_fatal():
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "test_file", "jalon3", "tp31.test"))
+    rt.RayTracer.new(cfg)
+    f = cfg.frame()
+    f.width = 0
+    with pytest.raises(rt.RtError, match="greater than zero"):
+        rt.render(f)
+    with pytest.raises(rt.RtError, match="bad shard"):
+        rt.render_tiles(cfg.frame(), 3, 2, 0)
