@@ -14,6 +14,7 @@ librt_amd.so (hand-written gfx950 kernels).  There is no CPU or PyTorch fallback
 library is missing or no GPU is usable the calls raise.
 """
 import ctypes as C
+import importlib.util
 import os
 
 import numpy as np
@@ -102,12 +103,29 @@ _SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (same soname as /opt/rocm's).  Two HIP
+    runtimes in one process do not work (the second one finds no GPU), so when torch is
+    installed its copy is loaded first and librt_amd.so binds to it by soname.  Buffers and
+    streams can then be shared with torch (RCCL collectives on rendered tiles)."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded librt_amd.so.  Raises when it has not been built: there is no fallback."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (or __graft_entry__.build())")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError here = header and library disagree
