@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: the dragon scene (final_avec_bonus.scene, 100 000 triangles + a mirror
+plane, 2 point lights, maxdepth 5) rendered at 3840x2160 on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one frame.  With N ranks the frame is cut into interleaved 8-row tiles (tile t ->
+rank t % N), every rank renders its tiles with the scene replicated by one RCCL broadcast
+(outside the timed region, like the reference's BVH build, src/main.rs:11-15), and each frame
+ends with one RCCL gather of the compact row buffers to rank 0, which restores frame order.
+The total work is fixed as N grows: "scaling": "strong".
+
+Rank 0 prints ONE JSON line.  `value` counts primary + shadow rays per second (the wording of
+the metric); reflection rays are traced too and reported in `mrays_all_per_s`.  Ray counts are
+deterministic and come from an instrumented render outside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import __graft_entry__ as ge  # noqa: E402
+
+SCENE = os.path.join(ROOT, "tests", "golden", "final_avec_bonus.scene")
+WIDTH, HEIGHT = 3840, 2160
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
+L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth measured on MI355X (the dragon's 8 MB working set is cache resident)
+
+
+def cpu_baseline(oracle, width, height):
+    """The oracle timed on this host: the reference's algorithm (collect every candidate of the
+    tree, test them all; raytracer.rs:110-159) and the pruned variant, on every 4th row tile of
+    the same frame."""
+    sc = oracle.OracleScene.load(SCENE)
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
+    out = {}
+    for name, mode in (("reference_faithful", oracle.OracleScene.MODE_TREE_COLLECT), ("pruned", oracle.OracleScene.MODE_TREE_PRUNED)):
+        sc.render_tiles(0, 64, width=width, height=height, mode=mode, threads=threads)      # builds the tree, warms up
+        _, st = sc.render_tiles(0, 4, width=width, height=height, mode=mode, threads=threads)
+        sec = st["render_ms"] / 1e3
+        out[name] = {"mrays_primary_shadow_per_s": (st["primary"] + st["shadow"]) / sec / 1e6,
+                     "mrays_all_per_s": (st["primary"] + st["shadow"] + st["secondary"]) / sec / 1e6,
+                     "seconds": sec}
+    return {"value": out["reference_faithful"]["mrays_primary_shadow_per_s"], "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"every 4th 8-row tile of the {width}x{height} dragon frame (540 rows), C++ restatement of the reference, "
+                      f"bit-exact vs dragon3.png; candidate collection as raytracer.rs:110-159",
+            "all_rays_value": out["reference_faithful"]["mrays_all_per_s"], "seconds": out["reference_faithful"]["seconds"],
+            "pruned_variant": out["pruned"]}
+
+
+def load_traffic(workload):
+    """HBM traffic per launch from the committed PMC passes (profiles/), if they are for this workload."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(p) as fh:
+            t = json.load(fh)
+        if t.get("workload") == workload:
+            return t.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    rt = ge.load_package()
+    import importlib
+    shard_mod = importlib.import_module("raytracer_rust_amd.distributed")
+
+    cfg = None
+    if rank == 0:
+        cfg = rt.ParsedConfigState().load_config_file(SCENE)
+        cfg.set_size(args.width, args.height)
+    t_up = time.perf_counter()
+    renderer = shard_mod.ShardedRenderer(rt, local_rank, scene=cfg.scene() if rank == 0 else None)
+    upload_s = time.perf_counter() - t_up
+
+    # Every rank needs the frame constants; they are 22 numbers, computed on the host (tanf).
+    if world > 1:
+        fr = torch.zeros(22, dtype=torch.float64, device=renderer.device)
+        if rank == 0:
+            f = cfg.frame()
+            vals = list(f.pos) + list(f.cv) + list(f.right) + list(f.up) + [f.pixel_w, f.pixel_h, f.half_w, f.half_h,
+                                                                         f.width, f.height, f.maxdepth] + list(f.ambient)
+            fr = torch.tensor(vals, dtype=torch.float64, device=renderer.device)
+        dist.broadcast(fr, src=0)
+        v = fr.cpu().tolist()
+        frame = rt.rt_frame()
+        for i in range(3):
+            frame.pos[i], frame.cv[i], frame.right[i], frame.up[i], frame.ambient[i] = v[i], v[3 + i], v[6 + i], v[9 + i], v[19 + i]
+        frame.pixel_w, frame.pixel_h, frame.half_w, frame.half_h = v[12:16]
+        frame.width, frame.height, frame.maxdepth = int(v[16]), int(v[17]), int(v[18])
+    else:
+        frame = cfg.frame()
+
+    W, H = frame.width, frame.height
+    # Work of this rank's shard (deterministic): instrumented kernel, outside the timed region.
+    stride, local, gathered, full = renderer._buffers(W, H)
+    target = full if world == 1 else local
+    st = rt.render_tiles(frame, rank, world, target.data_ptr(), count_work=True)
+    counts = torch.tensor([st["primary"], st["shadow"], st["secondary"], st["nodes_visited"], st["prims_tested"]],
+                          dtype=torch.int64, device=renderer.device)
+    mine = counts.clone()
+    if world > 1:
+        dist.all_reduce(counts)
+    primary, shadow, secondary, nodes, prims = (int(x) for x in counts.cpu().tolist())
+
+    def sync_all():
+        rt.synchronize()
+        torch.cuda.synchronize(renderer.device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(renderer.device)
+
+    for _ in range(args.warmup):
+        renderer.render_frame(frame)
+    sync_all()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        # HIP events on the stream the kernel is launched on (the library's stream, wrapped for torch).
+        ev[i][0].record(renderer.ext_stream)
+        out = renderer.render_frame(frame)
+        ev[i][1].record(renderer.ext_stream)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=renderer.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # Kernel-only duration of this rank's render launches, measured separately with events
+    # bracketing just the kernel (the loop above brackets kernel + gather + assemble).
+    kernel_ms = []
+    for _ in range(min(args.steps, 10)):
+        s = rt.render_tiles(frame, rank, world, target.data_ptr(), want_stats=True)
+        kernel_ms.append(s["kernel_ms"])
+    step_ms_events = [a.elapsed_time(b) for a, b in ev]
+
+    if rank == 0:
+        frame_host = renderer.frame_to_host(out)
+        checksum = int(np.bitwise_xor.reduce(frame_host.reshape(-1).astype(np.uint64) * np.arange(1, frame_host.size + 1, dtype=np.uint64)))
+        ms_per_step = elapsed / args.steps * 1e3
+        rays_ps = primary + shadow
+        rays_all = primary + shadow + secondary
+        k_ms = float(np.mean(kernel_ms))
+        my_primary, _, _, my_nodes, my_prims = (int(x) for x in mine.cpu().tolist())
+        alg_bytes = 32 * my_nodes + 48 * my_prims + 4 * my_primary      # per launch of this rank's kernel
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        workload = f"final_avec_bonus.scene (dragon, 100000 triangles + plane, 2 point lights, maxdepth 5) at {W}x{H}"
+        result = {
+            "metric": "Mrays/sec (primary+shadow) at 3840x2160 dragon scene",
+            "value": rays_ps * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "reference scene file final_avec_bonus.scene with the size line overridden to 3840 2160" if (W, H) == (WIDTH, HEIGHT)
+                    else f"reference scene file final_avec_bonus.scene at {W}x{H}",
+            "config": {"workload": workload, "tile_rows": rt.TILE_ROWS, "sharding": f"interleaved row tiles over {world} GPU(s), gather to rank 0"},
+            "frames_per_s": args.steps / elapsed,
+            "mrays_all_per_s": rays_all * args.steps / elapsed / 1e6,
+            "rays_per_frame": {"primary": primary, "shadow": shadow, "reflection": secondary},
+            "work_per_frame": {"boxes_tested": nodes, "shapes_tested": prims},
+            "bvh": renderer.bvh_info,
+            "scene_upload_s": upload_s,
+            "step_ms_hip_events_mean": float(np.mean(step_ms_events)),
+            "frame_checksum": checksum,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": load_traffic(workload),
+                         "kernel": "render_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac_of_l2_peak": achieved / L2_PEAK_GBS,
+                         "note": "algorithmic bytes = 32 B x boxes tested + 48 B x shapes tested + 4 B x pixels; the 8 MB scene is "
+                                 "L2/Infinity-Cache resident, so the rate is compared with HBM as the contract asks and with L2 for context"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(ge.load_oracle(), W, H)
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,6 +114,7 @@ int rt_get_bvh_info(rt_bvh_info* out);
  * a broadcast) and the inverse: adopt a blob that was received into device memory owned by
  * the caller, which must stay valid until the next upload/adopt/shutdown. */
 int rt_scene_blob(void** device_ptr, size_t* bytes);
+int rt_copy_scene_blob(void* device_dst, size_t bytes);   /* device-to-device copy of the blob, waits for completion */
 int rt_adopt_scene_blob(void* device_ptr, size_t bytes);
 
 /* RayTracer::render (raytracer.rs:40-79): renders the whole frame into host memory,

@@ -54,6 +54,9 @@ def lib():
         L.oracle_render.restype = C.c_int
         L.oracle_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                     C.c_void_p, C.POINTER(OracleStats)]
+        L.oracle_render_tiles.restype = C.c_int
+        L.oracle_render_tiles.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                          C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(OracleStats)]
         L.oracle_compare.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.oracle_powf.restype = C.c_float
         L.oracle_powf.argtypes = [C.c_float, C.c_float]
@@ -151,6 +154,25 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError(lib().oracle_last_error().decode())
         return out, st.as_dict()
+
+
+def _render_tiles(self, shard, nshards, tile_rows=8, width=0, height=0, mode=0, threads=0):
+    """Rows of the interleaved tiles owned by `shard`, compact: (pixels[rows, W], stats)."""
+    i = self.info()
+    w, h = (width or i["width"]), (height or i["height"])
+    n = C.c_uint32()
+    rc = lib().oracle_render_tiles(self._h, w, h, shard, nshards, tile_rows, mode, threads, None, C.byref(n), None)
+    if rc != 0:
+        raise RuntimeError(lib().oracle_last_error().decode())
+    out = np.zeros((n.value, w), dtype=np.uint32)
+    st = OracleStats()
+    rc = lib().oracle_render_tiles(self._h, w, h, shard, nshards, tile_rows, mode, threads, out.ctypes.data, C.byref(n), C.byref(st))
+    if rc != 0:
+        raise RuntimeError(lib().oracle_last_error().decode())
+    return out, st.as_dict()
+
+
+OracleScene.render_tiles = _render_tiles
 
 
 def compare(a, b):

@@ -716,16 +716,9 @@ void oracle_frame_setup(void* h, uint32_t W, uint32_t H, float* out16) {
     out16[12] = f.pw; out16[13] = f.ph; out16[14] = f.w2; out16[15] = f.h2;
 }
 
-// Render rows [row0, row0+nrows) of a W x H frame (W = H = 0: the scene's own size) into
-// out[nrows * W] (0xFFRRGGBB, row-major, first row on top).
-// mode 0: every shape is a candidate (ground truth)
-// mode 1: tree, collect every candidate, then test them all (what raytracer.rs:110-159 does)
-// mode 2: tree with distance pruning and shadow early exit
-int oracle_render(void* h, uint32_t W, uint32_t H, uint32_t row0, uint32_t nrows, int mode, int threads,
-                  uint32_t* out, oracle_stats* stats) {
-    Scene* sc = (Scene*)h;
-    if (W == 0 || H == 0) { W = sc->width; H = sc->height; }
-    if (row0 + nrows > H) { g_err = "row range outside the frame"; return 1; }
+namespace {
+int render_rows(Scene* sc, uint32_t W, uint32_t H, const std::vector<uint32_t>& rows, int mode, int threads,
+                uint32_t* out, oracle_stats* stats) {
     if (mode < 0 || mode > 2) { g_err = "unknown mode"; return 1; }
     if (mode == MODE_TREE_COLLECT) build_tree(*sc, 1);
     if (mode == MODE_TREE_PRUNED) build_tree(*sc, 4);
@@ -737,8 +730,8 @@ int oracle_render(void* h, uint32_t W, uint32_t H, uint32_t row0, uint32_t nrows
     {
         Tracer tr(*sc, mode);
 #pragma omp for schedule(dynamic, 1)
-        for (int64_t yy = 0; yy < (int64_t)nrows; yy++) {
-            uint32_t y = row0 + (uint32_t)yy;
+        for (int64_t yy = 0; yy < (int64_t)rows.size(); yy++) {
+            uint32_t y = rows[(size_t)yy];
             float b = (f.ph * (f.h2 - ((float)y + 0.5f))) / f.h2;                      // raytracer.rs:61
             for (uint32_t x = 0; x < W; x++) {
                 float a = (f.pw * (((float)x + 0.5f) - f.w2)) / f.w2;                  // raytracer.rs:64
@@ -759,6 +752,37 @@ int oracle_render(void* h, uint32_t W, uint32_t H, uint32_t row0, uint32_t nrows
         stats->render_ms = (t1 - t0) * 1e3; stats->threads = threads;
     }
     return 0;
+}
+}  // namespace
+
+// Render rows [row0, row0+nrows) of a W x H frame (W = H = 0: the scene's own size) into
+// out[nrows * W] (0xFFRRGGBB, row-major, first row on top).
+// mode 0: every shape is a candidate (ground truth)
+// mode 1: tree, collect every candidate, then test them all (what raytracer.rs:110-159 does)
+// mode 2: tree with distance pruning and shadow early exit
+int oracle_render(void* h, uint32_t W, uint32_t H, uint32_t row0, uint32_t nrows, int mode, int threads,
+                  uint32_t* out, oracle_stats* stats) {
+    Scene* sc = (Scene*)h;
+    if (W == 0 || H == 0) { W = sc->width; H = sc->height; }
+    if (row0 + nrows > H) { g_err = "row range outside the frame"; return 1; }
+    std::vector<uint32_t> rows(nrows);
+    for (uint32_t i = 0; i < nrows; i++) rows[i] = row0 + i;
+    return render_rows(sc, W, H, rows, mode, threads, out, stats);
+}
+
+// Render the interleaved row tiles of one shard: tile t (tile_rows rows) belongs to shard
+// t % nshards; the shard's rows are written compactly in increasing order.  Returns the
+// number of rows through *nrows_out (out may be NULL to only ask for it).
+int oracle_render_tiles(void* h, uint32_t W, uint32_t H, uint32_t shard, uint32_t nshards, uint32_t tile_rows, int mode,
+                        int threads, uint32_t* out, uint32_t* nrows_out, oracle_stats* stats) {
+    Scene* sc = (Scene*)h;
+    if (W == 0 || H == 0) { W = sc->width; H = sc->height; }
+    if (nshards == 0 || shard >= nshards || tile_rows == 0) { g_err = "bad shard description"; return 1; }
+    std::vector<uint32_t> rows;
+    for (uint32_t y = 0; y < H; y++) if ((y / tile_rows) % nshards == shard) rows.push_back(y);
+    if (nrows_out) *nrows_out = (uint32_t)rows.size();
+    if (!out) return 0;
+    return render_rows(sc, W, H, rows, mode, threads, out, stats);
 }
 
 // Image::compare (imgcomparator/mod.rs:54-89) plus the two statistics the parity target is

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "rt_upload_scene": (C.c_int, [C.POINTER(rt_scene)]),
     "rt_get_bvh_info": (C.c_int, [C.POINTER(rt_bvh_info)]),
     "rt_scene_blob": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "rt_copy_scene_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rt_adopt_scene_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rt_render": (C.c_int, [C.POINTER(rt_frame), C.c_void_p, C.POINTER(rt_stats), C.c_int]),
     "rt_render_tiles": (C.c_int, [C.POINTER(rt_frame), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(rt_stats), C.c_int]),
@@ -341,6 +342,10 @@ def scene_blob():
     p, n = C.c_void_p(), C.c_size_t()
     _check(lib().rt_scene_blob(C.byref(p), C.byref(n)))
     return p.value, n.value
+
+
+def copy_scene_blob(device_dst, nbytes):
+    _check(lib().rt_copy_scene_blob(C.c_void_p(device_dst), nbytes))
 
 
 def adopt_scene_blob(device_ptr, nbytes):

@@ -206,6 +206,15 @@ int rt_scene_blob(void** device_ptr, size_t* bytes) {
     return 0;
 }
 
+int rt_copy_scene_blob(void* device_dst, size_t bytes) {
+    if (!g.have_scene) return fail("no scene uploaded");
+    if (!device_dst || bytes != g.blob_bytes) return fail("rt_copy_scene_blob: destination must be exactly the blob size");
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipMemcpyAsync(device_dst, g.d_blob, bytes, hipMemcpyDeviceToDevice, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
 int rt_adopt_scene_blob(void* device_ptr, size_t bytes) {
     if (!g.inited) return fail("rt_init has not been called");
     if (!device_ptr || bytes < sizeof(rtl::BlobHeader)) return fail("rt_adopt_scene_blob: buffer too small");

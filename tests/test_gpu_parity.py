@@ -198,9 +198,7 @@ def test_scene_blob_round_trip_replicates_the_scene():
     a = tracer.render().data.copy()
     ptr, nbytes = rt.scene_blob()
     copy = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    assert hip.hipMemcpy(ctypes.c_void_p(copy.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), 3) == 0
+    rt.copy_scene_blob(copy.data_ptr(), nbytes)
     rt.adopt_scene_blob(copy.data_ptr(), nbytes)
     b, _ = rt.render(cfg.frame())
     assert np.array_equal(a, b.reshape(-1))
