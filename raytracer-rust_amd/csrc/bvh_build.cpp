@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <omp.h>
@@ -20,8 +21,10 @@ namespace rtb {
 namespace {
 
 constexpr int NBINS = 32;
-constexpr float COST_TRAVERSE = 1.0f;   // one node pair fetch + two slab tests
-constexpr float COST_SHAPE = 1.0f;      // one exact shape test
+float env_float(const char* name, float dflt) { const char* e = std::getenv(name); return e ? (float)std::atof(e) : dflt; }
+const float COST_TRAVERSE = env_float("RT_AMD_BVH_COST_TRAVERSE", 1.0f);   // one node pair fetch + two slab tests
+const float COST_SHAPE = env_float("RT_AMD_BVH_COST_SHAPE", 1.0f);         // one exact shape test
+const uint32_t LEAF_CAP = std::min<uint32_t>(rtl::MAX_LEAF, (uint32_t)env_float("RT_AMD_BVH_MAX_LEAF", (float)rtl::MAX_LEAF));
 constexpr uint32_t PARALLEL_MIN = 8192; // subtrees above this size become OpenMP tasks
 
 struct Box {
@@ -128,12 +131,12 @@ struct Builder {
         }
         if (best_axis < 0) {
             // All centroids coincide: nothing to bin.  Keep a leaf if it fits, else halve by index.
-            if (count <= rtl::MAX_LEAF) return 0;
+            if (count <= LEAF_CAP) return 0;
             return first + count / 2;
         }
         float split_cost = COST_TRAVERSE + COST_SHAPE * (parent_area > 0.0f ? best_cost / parent_area : (float)count);
         float leaf_cost = COST_SHAPE * (float)count;
-        if (count <= rtl::MAX_LEAF && leaf_cost <= split_cost) return 0;
+        if (count <= LEAF_CAP && leaf_cost <= split_cost) return 0;
         float c0 = cb.lo[best_axis], c1 = cb.hi[best_axis];
         float scale = (float)NBINS / (c1 - c0);
         auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t s) {

@@ -12,7 +12,8 @@ struct DevScene {
     const float4* list;     // 3 float4 per always-tested shape
     const float4* mats;     // 2 float4 per material
     const float4* lights;   // 2 float4 per light
-    uint32_t n_list, n_lights, root_ref, pad;
+    uint32_t n_list, n_lights, root_ref;
+    uint32_t finite_shading;   // 1 when every material and light value is finite (lets zero contributions be skipped)
 };
 
 // rt_frame plus the shard this launch renders.

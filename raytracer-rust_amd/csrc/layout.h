@@ -55,7 +55,8 @@ struct BlobHeader {
     uint32_t root_ref;
     uint32_t max_depth, max_leaf, n_leaves;
     float sah_cost;
-    uint32_t pad[64 - 24];
+    uint32_t finite_shading;   // 1 when every material and light value is finite
+    uint32_t pad[64 - 25];
 };
 static_assert(sizeof(BlobHeader) == 256, "blob header must be 256 bytes");
 

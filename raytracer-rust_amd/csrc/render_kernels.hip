@@ -162,8 +162,10 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float tlim = best->prim == NO_PRIM ? INF : prune_limit(best->t);
     uint32_t sp = 0;
-    for (;;) {
-        if (!(cur & REF_LEAF)) {
+    // All lanes descend through inner nodes until each has reached a leaf (or run out of nodes),
+    // then all test their leaves together: fewer half-empty passes than alternating per step.
+    while (cur != REF_EMPTY) {
+        while (!(cur & REF_LEAF)) {
             const float4* n = sc.nodes + 4 * (size_t)cur;
             const float4 lo0 = n[0], hi0 = n[1], lo1 = n[2], hi1 = n[3];
             float t0, t1;
@@ -177,8 +179,10 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
                 cur = swap ? r1 : r0;
             } else if (h0) cur = r0;
             else if (h1) cur = r1;
-            else { if (sp == 0) break; sp--; cur = stack[sp * 64]; }
-        } else {
+            else if (sp == 0) cur = REF_EMPTY;
+            else { sp--; cur = stack[sp * 64]; }
+        }
+        if (cur != REF_EMPTY) {
             uint32_t first = (cur & ~REF_LEAF) >> 3, count = (cur & 7u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
                 const float4* p = sc.tree + 3 * (size_t)(first + k);
@@ -190,7 +194,8 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
                     tlim = prune_limit(best->t);
                 }
             }
-            if (sp == 0) break; sp--; cur = stack[sp * 64];
+            if (sp == 0) cur = REF_EMPTY;
+            else { sp--; cur = stack[sp * 64]; }
         }
     }
 }
@@ -218,8 +223,8 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float tlim = point_light ? prune_limit(light_dist) : INF;
     uint32_t sp = 0;
-    for (;;) {
-        if (!(cur & REF_LEAF)) {
+    while (cur != REF_EMPTY) {
+        while (!(cur & REF_LEAF)) {
             const float4* n = sc.nodes + 4 * (size_t)cur;
             const float4 lo0 = n[0], hi0 = n[1], lo1 = n[2], hi1 = n[3];
             float t0, t1;
@@ -230,17 +235,21 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
             if (h0 && h1) { stack[sp * 64] = r1; sp++; cur = r0; }
             else if (h0) cur = r0;
             else if (h1) cur = r1;
-            else { if (sp == 0) return false; sp--; cur = stack[sp * 64]; }
-        } else {
+            else if (sp == 0) cur = REF_EMPTY;
+            else { sp--; cur = stack[sp * 64]; }
+        }
+        if (cur != REF_EMPTY) {
             uint32_t first = (cur & ~REF_LEAF) >> 3, count = (cur & 7u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
                 const float4* p = sc.tree + 3 * (size_t)(first + k);
                 if (COUNT) cnt->prims++;
                 if (occludes(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
             }
-            if (sp == 0) return false; sp--; cur = stack[sp * 64];
+            if (sp == 0) cur = REF_EMPTY;
+            else { sp--; cur = stack[sp * 64]; }
         }
     }
+    return false;
 }
 
 __device__ __forceinline__ uint32_t quantise(V3 c) {                                             // raytracer.rs:85-91
@@ -322,8 +331,12 @@ __global__ __launch_bounds__(64) void render_kernel(DevScene sc, DevFrame f, uin
                     light_dir = v3(l0);
                 }
                 if (COUNT) cnt.shadow++;
-                if (in_shadow<COUNT>(sc, shadow_origin, light_dir, back, point_light, light_dist, stack, &cnt)) continue;
                 float n_dot_l = fmaxf(vdot(normal, light_dir), 0.0f);
+                // A light at or below the horizon of the surface adds (diffuse*0 + specular*0) (*) colour = +0
+                // whether or not it is occluded (unless shininess == 1, where the factor ignores n.l), so
+                // its shadow ray need not be traced.  Only valid while every factor is finite.
+                if (sc.finite_shading && n_dot_l == 0.0f && shininess != 1.0f) continue;
+                if (in_shadow<COUNT>(sc, shadow_origin, light_dir, back, point_light, light_dist, stack, &cnt)) continue;
                 V3 diffuse = vscale(diffuse_color, n_dot_l);
                 V3 view_dir = vneg(d);
                 V3 half_vector = vnormalize(vadd(light_dir, view_dir));

@@ -57,7 +57,7 @@ void point_at_blob(void* d_blob, const rtl::BlobHeader& h) {
     g.dsc.list = (const float4*)(base + h.off_list_shapes);
     g.dsc.mats = (const float4*)(base + h.off_materials);
     g.dsc.lights = (const float4*)(base + h.off_lights);
-    g.dsc.n_list = h.n_list_shapes; g.dsc.n_lights = h.n_lights; g.dsc.root_ref = h.root_ref; g.dsc.pad = 0;
+    g.dsc.n_list = h.n_list_shapes; g.dsc.n_lights = h.n_lights; g.dsc.root_ref = h.root_ref; g.dsc.finite_shading = h.finite_shading;
     g.info.node_pairs = h.n_pairs; g.info.leaves = h.n_leaves; g.info.max_depth = h.max_depth; g.info.max_leaf = h.max_leaf;
     g.info.bvh_prims = h.n_tree_shapes; g.info.list_prims = h.n_list_shapes; g.info.sah_cost = h.sah_cost;
     g.have_scene = true;

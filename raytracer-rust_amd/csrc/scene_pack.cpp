@@ -166,6 +166,12 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
     h.off_materials = off; off = align256(off + mats.size() * sizeof(rtl::MaterialRec));
     h.off_lights = off; off = align256(off + (size_t)s.nlights * sizeof(rtl::LightRec));
     h.total_bytes = off;
+    bool finite = true;
+    for (const rtl::MaterialRec& m : mats)
+        for (int k = 0; k < 3; k++) finite = finite && std::isfinite(m.diffuse[k]) && std::isfinite(m.specular[k]);
+    for (uint32_t i = 0; i < s.nlights; i++)
+        for (int k = 1; k < 7; k++) finite = finite && std::isfinite(s.lights[7 * (size_t)i + k]);
+    h.finite_shading = finite ? 1u : 0u;
     blob->assign(off, 0);
     std::memcpy(blob->data(), &h, sizeof(h));
     if (h.n_pairs) std::memcpy(blob->data() + h.off_nodes, bvh.pairs.data(), (size_t)h.n_pairs * sizeof(rtl::NodePair));
