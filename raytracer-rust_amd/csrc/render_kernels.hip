@@ -163,8 +163,10 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
     float tlim = best->prim == NO_PRIM ? INF : prune_limit(best->t);
     uint32_t sp = 0;
     // All lanes descend through inner nodes until each has reached a leaf (or run out of nodes),
-    // then all test their leaves together: fewer half-empty passes than alternating per step.
-    while (cur != REF_EMPTY) {
+    // then all test their leaves together.  A lane that reaches its leaf early sets it aside and
+    // keeps descending towards its next one instead of idling (it then tests both).
+    uint32_t held = 0;                                  // leaf set aside (leaf references are never 0)
+    for (;;) {
         while (!(cur & REF_LEAF)) {
             const float4* n = sc.nodes + 4 * (size_t)cur;
             const float4 lo0 = n[0], hi0 = n[1], lo1 = n[2], hi1 = n[3];
@@ -181,9 +183,18 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             else if (h1) cur = r1;
             else if (sp == 0) cur = REF_EMPTY;
             else { sp--; cur = stack[sp * 64]; }
+            if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {
+                held = cur;
+                if (sp == 0) cur = REF_EMPTY; else { sp--; cur = stack[sp * 64]; }
+            }
+            if (!__any(held == 0 && !(cur & REF_LEAF))) break;    // nobody is still looking for a first leaf
         }
-        if (cur != REF_EMPTY) {
-            uint32_t first = (cur & ~REF_LEAF) >> 3, count = (cur & 7u) + 1u;
+        if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf
+            held = cur;
+            if (sp == 0) cur = REF_EMPTY; else { sp--; cur = stack[sp * 64]; }
+        }
+        while (held != 0) {
+            uint32_t first = (held & ~REF_LEAF) >> 3, count = (held & 7u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
                 const float4* p = sc.tree + 3 * (size_t)(first + k);
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2];
@@ -194,9 +205,13 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
                     tlim = prune_limit(best->t);
                 }
             }
-            if (sp == 0) cur = REF_EMPTY;
-            else { sp--; cur = stack[sp * 64]; }
+            held = 0;
+            if ((cur & REF_LEAF) && cur != REF_EMPTY) {
+                held = cur;
+                if (sp == 0) cur = REF_EMPTY; else { sp--; cur = stack[sp * 64]; }
+            }
         }
+        if (cur == REF_EMPTY) break;
     }
 }
 
