@@ -7,13 +7,14 @@
 
 // Pointers into the resident scene blob (layout.h).
 struct DevScene {
-    const float4* nodes;    // 4 float4 per node pair
+    const uint4* nodes;     // 2 uint4 per node pair: {lo.x|lo.y<<16, lo.z|hi.x<<16, hi.y|hi.z<<16, ref} per child
     const float4* tree;     // 3 float4 per tree shape, leaves contiguous
     const float4* list;     // 3 float4 per always-tested shape
     const float4* mats;     // 2 float4 per material
     const float4* lights;   // 2 float4 per light
     uint32_t n_list, n_lights, root_ref;
     uint32_t finite_shading;   // 1 when every material and light value is finite (lets zero contributions be skipped)
+    float grid_origin[3], grid_scale[3];   // node box coordinate q on axis k = grid_origin[k] + q * grid_scale[k]
 };
 
 // rt_frame plus the shard this launch renders.

@@ -7,8 +7,13 @@
 //
 // every section 256-byte aligned.
 //
-//   node pair  64 B  two 32-byte child boxes side by side: {lo.xyz, ref} {hi.xyz, count} per
-//                    child.  One 64-byte fetch yields both boxes a traversal step needs.
+//   node pair  32 B  two 16-byte child records side by side: {lo.xyz, hi.xyz as 16-bit grid
+//                    coordinates, ref}.  The grid spans the box of all tree shapes with 65535
+//                    steps per axis (header: grid_origin, grid_scale); a coordinate q stands for
+//                    the plane origin + q * scale.  Boxes are rounded outwards onto the grid, so
+//                    they only grow (by less than one step: 0.0015 % of the scene extent).  One
+//                    16-byte load per child instead of two: the vector memory pipeline, not HBM,
+//                    is what bounds traversal of a cache-resident scene.
 //   shape      48 B  three float4.  q0.w carries kind | material << 2, q1.w the shape's
 //                    position in the scene file (tie break), q2.w is spare.
 //                      triangle: q0.xyz = v0, q1.xyz = v1, q2.xyz = v2   (raw vertices: the
@@ -35,9 +40,15 @@ constexpr uint32_t MAX_TREE_SHAPES = (1u << 28) - 2;
 
 inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return REF_LEAF | (first << 3) | (count - 1); }
 
+// Builder-side record (full precision), quantised by scene_pack.cpp into QuantPair.
 struct ChildBox { float lo[3]; uint32_t ref; float hi[3]; uint32_t count; };
 struct NodePair { ChildBox c[2]; };
-static_assert(sizeof(NodePair) == 64, "node pair must be 64 bytes");
+static_assert(sizeof(NodePair) == 64, "builder node pair is 64 bytes");
+
+struct QuantChild { uint16_t lo[3], hi[3]; uint32_t ref; };
+struct QuantPair { QuantChild c[2]; };
+static_assert(sizeof(QuantChild) == 16 && sizeof(QuantPair) == 32, "device node pair must be 32 bytes");
+constexpr float GRID_STEPS = 65535.0f;
 
 struct ShapeRec { float q0[3]; uint32_t kind_mat; float q1[3]; uint32_t order; float q2[3]; uint32_t spare; };
 static_assert(sizeof(ShapeRec) == 48, "shape record must be 48 bytes");
@@ -46,6 +57,7 @@ struct MaterialRec { float diffuse[3]; float shininess; float specular[3]; float
 struct LightRec { float v[3]; float kind; float color[3]; float pad; };
 
 constexpr uint32_t BLOB_MAGIC = 0x52544231u;   // "RTB1"
+constexpr uint32_t BLOB_VERSION = 2;
 
 struct BlobHeader {
     uint32_t magic, version;
@@ -56,7 +68,8 @@ struct BlobHeader {
     uint32_t max_depth, max_leaf, n_leaves;
     float sah_cost;
     uint32_t finite_shading;   // 1 when every material and light value is finite
-    uint32_t pad[64 - 25];
+    float grid_origin[3], grid_scale[3];   // node box coordinate q on axis k = grid_origin[k] + q * grid_scale[k]
+    uint32_t pad[64 - 31];
 };
 static_assert(sizeof(BlobHeader) == 256, "blob header must be 256 bytes");
 

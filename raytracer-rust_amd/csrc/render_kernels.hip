@@ -32,6 +32,11 @@
 
 #pragma clang fp contract(off)
 
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 5
+#endif
+#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
+
 namespace {
 
 using rtl::KIND_PLANE;
@@ -61,7 +66,10 @@ __device__ __forceinline__ V3 vcross(V3 a, V3 b) {
 __device__ __forceinline__ float vnorm(V3 a) { return sqrtf(vdot(a, a)); }
 __device__ __forceinline__ V3 vnormalize(V3 a) { float inv = 1.0f / vnorm(a); return vscale(a, inv); }
 
-struct Counters { uint32_t nodes, prims, shadow, secondary; };
+struct Counters { uint32_t nodes, prims, shadow, secondary, wave_node_iters, wave_prim_iters; };
+
+// True on exactly one of the currently active lanes.
+__device__ __forceinline__ bool first_active_lane() { return (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1); }
 
 // ------------------------------------------------------------------ exact shape tests
 // Each returns whether the reference's test yields Some(..) and the distance it would carry.
@@ -123,16 +131,48 @@ __device__ __forceinline__ bool shape_back_face(const float4 q0, const float4 q1
 }
 
 // ------------------------------------------------------------------ box culling (conservative)
-// Padded boxes, NaN-dropping min/max (a 0 * inf on a slab the origin lies on removes that
-// slab's constraint) and a relative slack on the far side cover the rounding of this test.
-__device__ __forceinline__ bool slab(const float4 lo, const float4 hi, V3 o, V3 inv, float tlim, float* tnear) {
-    float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
-    float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
-    float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
-    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tlim));
+// Node boxes are 16-bit coordinates on the scene grid: plane q on an axis is origin + q * scale.
+// Along a ray o + t d its parameter is (origin + q*scale - o) / d = q * A + B with, per ray and
+// axis, A = scale / d and B = (origin - o) / d, so one fused multiply-add per plane.  The
+// rounding of A, B and the multiply-add is bounded by delta = 2^-21 * (65535 |A| + |B|); B is
+// shifted by delta away from the interval on each side (the side is known from the sign of d),
+// so the computed interval always contains the exact one.  Nothing here decides a pixel: it
+// only has to keep every shape reachable that the exact tests would accept.
+struct RayBox { V3 A, Blo, Bhi; };
+
+__device__ __forceinline__ float safe_inverse(float d) {
+    // A zero (or denormal) direction component would make A and B infinite and their sum NaN;
+    // a huge finite slope keeps the slab semantics (inside: unbounded interval, outside: empty).
+    float inv = 1.0f / d;
+    return fminf(fmaxf(inv, -1e30f), 1e30f);
+}
+
+__device__ __forceinline__ RayBox make_raybox(const DevScene& sc, V3 o, V3 d) {
+    RayBox r;
+    const V3 inv = v3(safe_inverse(d.x), safe_inverse(d.y), safe_inverse(d.z));
+    r.A = v3(sc.grid_scale[0] * inv.x, sc.grid_scale[1] * inv.y, sc.grid_scale[2] * inv.z);
+    const V3 B = v3((sc.grid_origin[0] - o.x) * inv.x, (sc.grid_origin[1] - o.y) * inv.y, (sc.grid_origin[2] - o.z) * inv.z);
+    const float k = 4.76837158203125e-07f;   // 2^-21
+    const V3 delta = v3(k * (65535.0f * fabsf(r.A.x) + fabsf(B.x)), k * (65535.0f * fabsf(r.A.y) + fabsf(B.y)),
+                        k * (65535.0f * fabsf(r.A.z) + fabsf(B.z)));
+    // For d >= 0 the low plane is entered first: lower it (B - delta) and raise the high one.
+    r.Blo = v3(inv.x >= 0.0f ? B.x - delta.x : B.x + delta.x, inv.y >= 0.0f ? B.y - delta.y : B.y + delta.y,
+               inv.z >= 0.0f ? B.z - delta.z : B.z + delta.z);
+    r.Bhi = v3(inv.x >= 0.0f ? B.x + delta.x : B.x - delta.x, inv.y >= 0.0f ? B.y + delta.y : B.y - delta.y,
+               inv.z >= 0.0f ? B.z + delta.z : B.z - delta.z);
+    return r;
+}
+
+__device__ __forceinline__ bool slab(const uint4 c, const RayBox& rb, float tlim, float* tnear) {
+    const float lx = (float)(c.x & 0xFFFFu), ly = (float)(c.x >> 16), lz = (float)(c.y & 0xFFFFu);
+    const float hx = (float)(c.y >> 16), hy = (float)(c.z & 0xFFFFu), hz = (float)(c.z >> 16);
+    const float ax = fmaf(lx, rb.A.x, rb.Blo.x), bx = fmaf(hx, rb.A.x, rb.Bhi.x);
+    const float ay = fmaf(ly, rb.A.y, rb.Blo.y), by = fmaf(hy, rb.A.y, rb.Bhi.y);
+    const float az = fmaf(lz, rb.A.z, rb.Blo.z), bz = fmaf(hz, rb.A.z, rb.Bhi.z);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tlim));
     *tnear = tn;
-    return tn <= tf * 1.000001f;
+    return tn <= tf;
 }
 
 // Pruning bound for a closest hit at computed distance t: shapes whose computed distance could
@@ -159,7 +199,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
     }
     uint32_t cur = sc.root_ref;
     if (cur == REF_EMPTY) return;
-    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const RayBox rb = make_raybox(sc, o, d);
     float tlim = best->prim == NO_PRIM ? INF : prune_limit(best->t);
     uint32_t sp = 0;
     // All lanes descend through inner nodes until each has reached a leaf (or run out of nodes),
@@ -168,13 +208,13 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
     uint32_t held = 0;                                  // leaf set aside (leaf references are never 0)
     for (;;) {
         while (!(cur & REF_LEAF)) {
-            const float4* n = sc.nodes + 4 * (size_t)cur;
-            const float4 lo0 = n[0], hi0 = n[1], lo1 = n[2], hi1 = n[3];
+            const uint4* n = sc.nodes + 2 * (size_t)cur;
+            const uint4 c0 = n[0], c1 = n[1];
             float t0, t1;
-            bool h0 = slab(lo0, hi0, o, inv, tlim, &t0);
-            bool h1 = slab(lo1, hi1, o, inv, tlim, &t1);
-            if (COUNT) cnt->nodes += 2;
-            uint32_t r0 = __float_as_uint(lo0.w), r1 = __float_as_uint(lo1.w);
+            bool h0 = slab(c0, rb, tlim, &t0);
+            bool h1 = slab(c1, rb, tlim, &t1);
+            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) cnt->wave_node_iters++; }
+            uint32_t r0 = c0.w, r1 = c1.w;
             if (h0 && h1) {
                 bool swap = t1 < t0;
                 stack[sp * 64] = swap ? r0 : r1; sp++;
@@ -199,7 +239,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
                 const float4* p = sc.tree + 3 * (size_t)(first + k);
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2];
                 float t;
-                if (COUNT) cnt->prims++;
+                if (COUNT) { cnt->prims++; if (first_active_lane()) cnt->wave_prim_iters++; }
                 if (test_shape(q0, q1, q2, o, d, &t)) {
                     consider(best, t, first + k, __float_as_uint(q1.w));
                     tlim = prune_limit(best->t);
@@ -235,18 +275,18 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
     }
     uint32_t cur = sc.root_ref;
     if (cur == REF_EMPTY) return false;
-    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const RayBox rb = make_raybox(sc, o, d);
     float tlim = point_light ? prune_limit(light_dist) : INF;
     uint32_t sp = 0;
     while (cur != REF_EMPTY) {
         while (!(cur & REF_LEAF)) {
-            const float4* n = sc.nodes + 4 * (size_t)cur;
-            const float4 lo0 = n[0], hi0 = n[1], lo1 = n[2], hi1 = n[3];
+            const uint4* n = sc.nodes + 2 * (size_t)cur;
+            const uint4 c0 = n[0], c1 = n[1];
             float t0, t1;
-            bool h0 = slab(lo0, hi0, o, inv, tlim, &t0);
-            bool h1 = slab(lo1, hi1, o, inv, tlim, &t1);
-            if (COUNT) cnt->nodes += 2;
-            uint32_t r0 = __float_as_uint(lo0.w), r1 = __float_as_uint(lo1.w);
+            bool h0 = slab(c0, rb, tlim, &t0);
+            bool h1 = slab(c1, rb, tlim, &t1);
+            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) cnt->wave_node_iters++; }
+            uint32_t r0 = c0.w, r1 = c1.w;
             if (h0 && h1) { stack[sp * 64] = r1; sp++; cur = r0; }
             else if (h0) cur = r0;
             else if (h1) cur = r1;
@@ -257,7 +297,7 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
             uint32_t first = (cur & ~REF_LEAF) >> 3, count = (cur & 7u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
                 const float4* p = sc.tree + 3 * (size_t)(first + k);
-                if (COUNT) cnt->prims++;
+                if (COUNT) { cnt->prims++; if (first_active_lane()) cnt->wave_prim_iters++; }
                 if (occludes(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
             }
             if (sp == 0) cur = REF_EMPTY;
@@ -283,7 +323,7 @@ __device__ __forceinline__ uint32_t frame_row(const DevFrame& f, uint32_t r) {
 }
 
 template <int STACK, bool COUNT>
-__global__ __launch_bounds__(64) void render_kernel(DevScene sc, DevFrame f, uint32_t* __restrict__ out, float4* __restrict__ fold,
+__global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, DevFrame f, uint32_t* __restrict__ out, float4* __restrict__ fold,
                                                     unsigned long long* __restrict__ counters) {
     __shared__ uint32_t s_stack[STACK * 64];
     const uint32_t lane = threadIdx.x;
@@ -291,7 +331,7 @@ __global__ __launch_bounds__(64) void render_kernel(DevScene sc, DevFrame f, uin
     const uint32_t tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
     const uint32_t x = tile_x * 8u + (lane & 7u), r = tile_y * 8u + (lane >> 3);
     uint32_t* stack = s_stack + lane;
-    Counters cnt = {0u, 0u, 0u, 0u};
+    Counters cnt = {0u, 0u, 0u, 0u, 0u, 0u};
     const bool live = x < f.width && r < f.local_rows;
     if (live) {
         const uint32_t y = frame_row(f, r);
@@ -383,8 +423,8 @@ __global__ __launch_bounds__(64) void render_kernel(DevScene sc, DevFrame f, uin
         out[pix] = quantise(cur);
     }
     if (COUNT) {
-        unsigned long long v[4] = {cnt.nodes, cnt.prims, cnt.shadow, cnt.secondary};
-        for (int k = 0; k < 4; k++) {
+        unsigned long long v[6] = {cnt.nodes, cnt.prims, cnt.shadow, cnt.secondary, cnt.wave_node_iters, cnt.wave_prim_iters};
+        for (int k = 0; k < 6; k++) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&counters[k], s);

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -52,12 +53,13 @@ void release_scene() {
 void point_at_blob(void* d_blob, const rtl::BlobHeader& h) {
     const char* base = (const char*)d_blob;
     g.hdr = h;
-    g.dsc.nodes = (const float4*)(base + h.off_nodes);
+    g.dsc.nodes = (const uint4*)(base + h.off_nodes);
     g.dsc.tree = (const float4*)(base + h.off_tree_shapes);
     g.dsc.list = (const float4*)(base + h.off_list_shapes);
     g.dsc.mats = (const float4*)(base + h.off_materials);
     g.dsc.lights = (const float4*)(base + h.off_lights);
     g.dsc.n_list = h.n_list_shapes; g.dsc.n_lights = h.n_lights; g.dsc.root_ref = h.root_ref; g.dsc.finite_shading = h.finite_shading;
+    for (int k = 0; k < 3; k++) { g.dsc.grid_origin[k] = h.grid_origin[k]; g.dsc.grid_scale[k] = h.grid_scale[k]; }
     g.info.node_pairs = h.n_pairs; g.info.leaves = h.n_leaves; g.info.max_depth = h.max_depth; g.info.max_leaf = h.max_leaf;
     g.info.bvh_prims = h.n_tree_shapes; g.info.list_prims = h.n_list_shapes; g.info.sah_cost = h.sah_cost;
     g.have_scene = true;
@@ -101,7 +103,7 @@ int render_shard(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32
     size_t npix = (size_t)local_rows * frame->width;
     uint32_t levels = frame->maxdepth > 1 ? frame->maxdepth - 1 : 0;
     if (ensure_fold(npix * (size_t)levels)) return 1;
-    if (count_work) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 4 * sizeof(unsigned long long), g.stream));
+    if (count_work) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 8 * sizeof(unsigned long long), g.stream));
     if (stats) HIP_TRY(hipEventRecord(g.ev0, g.stream));
     HIP_TRY(rtk_launch_render(&g.dsc, &f, d_out, g.d_fold, g.d_counters, (int)g.hdr.max_depth, count_work, g.stream));
     if (stats) {
@@ -112,9 +114,12 @@ int render_shard(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32
         stats->kernel_ms = ms;
         stats->primary = npix;
         if (count_work) {
-            unsigned long long c[4];
+            unsigned long long c[8];
             HIP_TRY(hipMemcpy(c, g.d_counters, sizeof(c), hipMemcpyDeviceToHost));
             stats->nodes_visited = c[0]; stats->prims_tested = c[1]; stats->shadow = c[2]; stats->secondary = c[3];
+            if (std::getenv("RT_AMD_PRINT_DIVERGENCE"))
+                std::fprintf(stderr, "wave-level passes: node loop %llu (lane use %.3f), shape loop %llu (lane use %.3f)\n", c[4],
+                             c[4] ? (double)c[0] / 2.0 / (64.0 * (double)c[4]) : 0.0, c[5], c[5] ? (double)c[1] / (64.0 * (double)c[5]) : 0.0);
         }
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -168,7 +173,7 @@ int rt_init(int device) {
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g.ev0));
     HIP_TRY(hipEventCreate(&g.ev1));
-    HIP_TRY(hipMalloc((void**)&g.d_counters, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&g.d_counters, 8 * sizeof(unsigned long long)));
     g.device = device; g.inited = true;
     return 0;
 }

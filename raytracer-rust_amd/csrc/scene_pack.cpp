@@ -53,10 +53,10 @@ void fill_record(const rt_scene& s, const Flat& f, rtl::ShapeRec* r) {
 }  // namespace
 
 bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err) {
-    if (h.magic != rtl::BLOB_MAGIC || h.version != 1) { *err = "scene blob: bad magic or version"; return false; }
+    if (h.magic != rtl::BLOB_MAGIC || h.version != rtl::BLOB_VERSION) { *err = "scene blob: bad magic or version"; return false; }
     if (h.total_bytes != bytes) { *err = "scene blob: size does not match its header"; return false; }
     auto fits = [&](uint64_t off, uint64_t n, uint64_t each) { return off % 16 == 0 && off >= sizeof(rtl::BlobHeader) && off + n * each <= bytes; };
-    if (!fits(h.off_nodes, h.n_pairs, sizeof(rtl::NodePair)) || !fits(h.off_tree_shapes, h.n_tree_shapes, sizeof(rtl::ShapeRec)) ||
+    if (!fits(h.off_nodes, h.n_pairs, sizeof(rtl::QuantPair)) || !fits(h.off_tree_shapes, h.n_tree_shapes, sizeof(rtl::ShapeRec)) ||
         !fits(h.off_list_shapes, h.n_list_shapes, sizeof(rtl::ShapeRec)) || !fits(h.off_materials, h.n_materials, sizeof(rtl::MaterialRec)) ||
         !fits(h.off_lights, h.n_lights, sizeof(rtl::LightRec))) {
         *err = "scene blob: section outside the buffer";
@@ -150,17 +150,39 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
         pad_abs = extent * 4e-6f;
     }
 
+    // Shapes far larger than the bulk of the scene (a ground sphere of radius 10000 under unit
+    // spheres) would stretch the 16-bit node grid for everybody: when there are only a few, they
+    // join the always-tested list instead of the tree.
+    if (nt > 0 && pad_abs > 0.0f) {
+        const float extent = pad_abs / 4e-6f;
+        std::vector<size_t> big;
+        for (size_t j = 0; j < nt && big.size() <= SMALL_SCENE; j++)
+            for (int k = 0; k < 3; k++)
+                if (hi[3 * j + k] - lo[3 * j + k] > 32.0f * extent) { big.push_back(j); break; }
+        if (!big.empty() && big.size() <= SMALL_SCENE && nt - big.size() > SMALL_SCENE) {
+            for (size_t b = big.size(); b-- > 0;) {
+                size_t j = big[b];
+                list_shapes.push_back(tree_in[j]);
+                tree_in.erase(tree_in.begin() + (ptrdiff_t)j);
+                lo.erase(lo.begin() + 3 * (ptrdiff_t)j, lo.begin() + 3 * (ptrdiff_t)j + 3);
+                hi.erase(hi.begin() + 3 * (ptrdiff_t)j, hi.begin() + 3 * (ptrdiff_t)j + 3);
+            }
+            nt = tree_in.size();
+            std::sort(list_shapes.begin(), list_shapes.end(), [](const Flat& a, const Flat& b) { return a.order < b.order; });
+        }
+    }
+
     rtb::BvhResult bvh;
     if (!rtb::build_bvh(lo.data(), hi.data(), (uint32_t)nt, TREE_DEPTH_LIMIT, pad_abs, &bvh, err)) return false;
 
     // Assemble the blob.
     rtl::BlobHeader h{};
-    h.magic = rtl::BLOB_MAGIC; h.version = 1;
+    h.magic = rtl::BLOB_MAGIC; h.version = rtl::BLOB_VERSION;
     h.n_pairs = (uint32_t)bvh.pairs.size(); h.n_tree_shapes = (uint32_t)nt; h.n_list_shapes = (uint32_t)list_shapes.size();
     h.n_materials = (uint32_t)mats.size(); h.n_lights = s.nlights;
     h.root_ref = bvh.root_ref; h.max_depth = bvh.max_depth; h.max_leaf = bvh.max_leaf; h.n_leaves = bvh.n_leaves; h.sah_cost = (float)bvh.sah_cost;
     size_t off = sizeof(rtl::BlobHeader);
-    h.off_nodes = off; off = align256(off + (size_t)h.n_pairs * sizeof(rtl::NodePair));
+    h.off_nodes = off; off = align256(off + (size_t)h.n_pairs * sizeof(rtl::QuantPair));
     h.off_tree_shapes = off; off = align256(off + nt * sizeof(rtl::ShapeRec));
     h.off_list_shapes = off; off = align256(off + list_shapes.size() * sizeof(rtl::ShapeRec));
     h.off_materials = off; off = align256(off + mats.size() * sizeof(rtl::MaterialRec));
@@ -173,8 +195,46 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
         for (int k = 1; k < 7; k++) finite = finite && std::isfinite(s.lights[7 * (size_t)i + k]);
     h.finite_shading = finite ? 1u : 0u;
     blob->assign(off, 0);
-    std::memcpy(blob->data(), &h, sizeof(h));
-    if (h.n_pairs) std::memcpy(blob->data() + h.off_nodes, bvh.pairs.data(), (size_t)h.n_pairs * sizeof(rtl::NodePair));
+    // Quantise the (already padded) builder boxes outwards onto the 16-bit scene grid.
+    {
+        double glo[3] = {0, 0, 0}, ghi[3] = {0, 0, 0};
+        bool first = true;
+        for (const rtl::NodePair& p : bvh.pairs)
+            for (int c = 0; c < 2; c++)
+                for (int k = 0; k < 3; k++) {
+                    if (first) { glo[k] = p.c[c].lo[k]; ghi[k] = p.c[c].hi[k]; }
+                    else { glo[k] = std::min<double>(glo[k], p.c[c].lo[k]); ghi[k] = std::max<double>(ghi[k], p.c[c].hi[k]); }
+                    if (c == 1 && k == 2) first = false;
+                }
+        for (int k = 0; k < 3; k++) {
+            h.grid_origin[k] = std::nextafter((float)glo[k], -INFINITY);
+            float sc = (float)((ghi[k] - (double)h.grid_origin[k]) / (double)rtl::GRID_STEPS);
+            sc = std::nextafter(std::nextafter(sc, INFINITY), INFINITY);
+            if (!(sc > 1e-30f)) sc = 1e-30f;
+            h.grid_scale[k] = sc;
+        }
+        rtl::QuantPair* qp = (rtl::QuantPair*)(blob->data() + h.off_nodes);
+        bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok) if (h.n_pairs > 100000)
+        for (int64_t i = 0; i < (int64_t)h.n_pairs; i++) {
+            for (int c = 0; c < 2; c++) {
+                const rtl::ChildBox& b = bvh.pairs[(size_t)i].c[c];
+                for (int k = 0; k < 3; k++) {
+                    const double o = h.grid_origin[k], sc = h.grid_scale[k];
+                    double ql = std::floor(((double)b.lo[k] - o) / sc), qh = std::ceil(((double)b.hi[k] - o) / sc);
+                    while (ql > 0 && o + ql * sc > (double)b.lo[k]) ql -= 1;         // the grid plane must not lie inside the box
+                    while (qh < rtl::GRID_STEPS && o + qh * sc < (double)b.hi[k]) qh += 1;
+                    if (ql < 0) ql = 0;
+                    if (qh > rtl::GRID_STEPS) qh = rtl::GRID_STEPS;
+                    if (o + ql * sc > (double)b.lo[k] || o + qh * sc < (double)b.hi[k]) ok = false;
+                    qp[i].c[c].lo[k] = (uint16_t)ql; qp[i].c[c].hi[k] = (uint16_t)qh;
+                }
+                qp[i].c[c].ref = b.ref;
+            }
+        }
+        if (!ok) { *err = "internal: a node box does not fit the quantisation grid"; return false; }
+    }
+    std::memcpy(blob->data(), &h, sizeof(h));        // after the grid has been filled in
     rtl::ShapeRec* ts = (rtl::ShapeRec*)(blob->data() + h.off_tree_shapes);
 #pragma omp parallel for schedule(static) if (nt > 100000)
     for (int64_t j = 0; j < (int64_t)nt; j++) fill_record(s, tree_in[bvh.order[j]], &ts[j]);

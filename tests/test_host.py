@@ -202,24 +202,29 @@ def test_compare_fixture_images():
 
 
 # ------------------------------------------------------------------ tree builder / blob
-HDR = struct.Struct("<IIQ5Q5II3If")
+HDR = struct.Struct("<IIQ5Q5II3IfI3f3f")
 
 
 def _read_blob(blob):
     (magic, ver, total, o_nodes, o_tree, o_list, o_mat, o_light, n_pairs, n_tree, n_list, n_mat, n_light, root,
-     max_depth, max_leaf, n_leaves, sah) = HDR.unpack_from(blob.tobytes()[:HDR.size])
-    assert magic == 0x52544231 and ver == 1 and total == len(blob)
-    nodes = blob[o_nodes:o_nodes + 64 * n_pairs].view(np.uint32).reshape(n_pairs, 16)
+     max_depth, max_leaf, n_leaves, sah, finite, gx, gy, gz, sx, sy, sz) = HDR.unpack_from(blob.tobytes()[:HDR.size])
+    assert magic == 0x52544231 and ver == 2 and total == len(blob)
+    nodes = blob[o_nodes:o_nodes + 32 * n_pairs].view(np.uint32).reshape(n_pairs, 8)
     tree = blob[o_tree:o_tree + 48 * n_tree].view(np.uint32).reshape(n_tree, 12)
     lst = blob[o_list:o_list + 48 * n_list].view(np.uint32).reshape(n_list, 12)
     return dict(nodes=nodes, tree=tree, list=lst, root=root, max_depth=max_depth, max_leaf=max_leaf, n_leaves=n_leaves,
-                n_mat=n_mat, n_light=n_light)
+                n_mat=n_mat, n_light=n_light, origin=np.float64([gx, gy, gz]), scale=np.float64([sx, sy, sz]))
 
 
 def _check_tree(b):
     nodes, tree = b["nodes"], b["tree"]
-    nf = nodes.view(np.float32)
     tf = tree.view(np.float32)
+
+    def child_box(ref, c):
+        # 16-bit grid coordinates -> the exact planes they stand for (float64: exact for these products)
+        w = nodes[ref, 4 * c:4 * c + 3]
+        q = np.float64([w[0] & 0xFFFF, w[0] >> 16, w[1] & 0xFFFF, w[1] >> 16, w[2] & 0xFFFF, w[2] >> 16])
+        return b["origin"] + q[:3] * b["scale"], b["origin"] + q[3:] * b["scale"]
     seen = np.zeros(len(tree), dtype=np.int32)
     max_depth = 0
     leaves = 0
@@ -252,12 +257,11 @@ def _check_tree(b):
             assert orders == sorted(orders)
             continue
         for c in (0, 1):
-            clo, chi = nf[ref, 8 * c:8 * c + 3], nf[ref, 8 * c + 4:8 * c + 7]
-            if lo is not None:
-                assert (clo >= lo - 1e-3 * np.abs(lo) - 1e-3).all() and (chi <= hi + 1e-3 * np.abs(hi) + 1e-3).all()
-            cref = int(nodes[ref, 8 * c + 3])
-            cnt = int(nodes[ref, 8 * c + 7])
-            assert cnt == ((cref & 7) + 1 if cref & 0x80000000 else 0)
+            clo, chi = child_box(ref, c)
+            if lo is not None:      # a child may stick out of its parent by the padding and one grid step, not more
+                slack = 2 * b["scale"] + 1e-5 * (np.abs(lo) + np.abs(hi)) + 1e-4 * (hi - lo).max()
+                assert (clo >= lo - slack).all() and (chi <= hi + slack).all()
+            cref = int(nodes[ref, 4 * c + 3])
             stack.append((cref, depth + 1, clo, chi))
     assert (seen == 1).all(), "every tree shape must sit in exactly one leaf"
     assert max_depth == b["max_depth"] <= 64 and leaves == b["n_leaves"]
@@ -267,8 +271,10 @@ def test_tree_of_test_scene_is_valid():
     cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "test.scene"))
     blob, info = rt.pack_scene_host(cfg.scene())
     b = _read_blob(blob)
-    assert info["bvh_prims"] == 266 and info["list_prims"] == 0 and len(b["tree"]) == 266
-    assert sorted(b["tree"][:, 7].tolist()) == list(range(266))
+    # the ground sphere of radius 10000 is kept out of the tree (it would stretch the node grid)
+    assert info["bvh_prims"] == 265 and info["list_prims"] == 1 and len(b["tree"]) == 265
+    assert sorted(b["tree"][:, 7].tolist() + b["list"][:, 7].tolist()) == list(range(266))
+    assert (b["list"][0][3] & 3) == 0 and b["list"].view(np.float32)[0][4] == 10000.0
     _check_tree(b)
 
 
