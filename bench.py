@@ -8,7 +8,8 @@ plane, 2 point lights, maxdepth 5) rendered at 3840x2160 on N MI355X.
 One step = one frame.  With N ranks the frame is cut into interleaved 8-row tiles (tile t ->
 rank t % N), every rank renders its tiles with the scene replicated by one RCCL broadcast
 (outside the timed region, like the reference's BVH build, src/main.rs:11-15), and each frame
-ends with one RCCL gather of the compact row buffers to rank 0, which restores frame order.
+ends with one RCCL gather of the compact row buffers to rank 0, which restores frame order
+(frames are pipelined two deep: the gather of one frame overlaps the kernel of the next).
 The total work is fixed as N grows: "scaling": "strong".
 
 Rank 0 prints ONE JSON line.  `value` counts primary + shadow rays per second (the wording of
@@ -102,7 +103,7 @@ def main():
         cfg = rt.ParsedConfigState().load_config_file(SCENE)
         cfg.set_size(args.width, args.height)
     t_up = time.perf_counter()
-    renderer = shard_mod.ShardedRenderer(rt, local_rank, scene=cfg.scene() if rank == 0 else None)
+    renderer, bvh_info = shard_mod.gpu_renderer(rt, local_rank, scene=cfg.scene() if rank == 0 else None)
     upload_s = time.perf_counter() - t_up
 
     # Every rank needs the frame constants; they are 22 numbers, computed on the host (tanf).
@@ -125,8 +126,8 @@ def main():
 
     W, H = frame.width, frame.height
     # Work of this rank's shard (deterministic): instrumented kernel, outside the timed region.
-    stride, local, gathered, full = renderer._buffers(W, H)
-    target = full if world == 1 else local
+    stride, local, gathered, full = renderer.buffers(W, H)
+    target = full if world == 1 else local[0]
     st = rt.render_tiles(frame, rank, world, target.data_ptr(), count_work=True)
     counts = torch.tensor([st["primary"], st["shadow"], st["secondary"], st["nodes_visited"], st["prims_tested"]],
                           dtype=torch.int64, device=renderer.device)
@@ -144,6 +145,7 @@ def main():
 
     for _ in range(args.warmup):
         renderer.render_frame(frame)
+    renderer.flush()
     sync_all()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -152,6 +154,7 @@ def main():
         ev[i][0].record(renderer.ext_stream)
         out = renderer.render_frame(frame)
         ev[i][1].record(renderer.ext_stream)
+    renderer.flush()          # the last frame's gather and reassembly belong to the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=renderer.device)
@@ -168,7 +171,7 @@ def main():
     step_ms_events = [a.elapsed_time(b) for a, b in ev]
 
     if rank == 0:
-        frame_host = renderer.frame_to_host(out)
+        frame_host = out.cpu().numpy().view(np.uint32)
         checksum = int(np.bitwise_xor.reduce(frame_host.reshape(-1).astype(np.uint64) * np.arange(1, frame_host.size + 1, dtype=np.uint64)))
         ms_per_step = elapsed / args.steps * 1e3
         rays_ps = primary + shadow
@@ -195,7 +198,7 @@ def main():
             "mrays_all_per_s": rays_all * args.steps / elapsed / 1e6,
             "rays_per_frame": {"primary": primary, "shadow": shadow, "reflection": secondary},
             "work_per_frame": {"boxes_tested": nodes, "shapes_tested": prims},
-            "bvh": renderer.bvh_info,
+            "bvh": bvh_info,
             "scene_upload_s": upload_s,
             "step_ms_hip_events_mean": float(np.mean(step_ms_events)),
             "frame_checksum": checksum,

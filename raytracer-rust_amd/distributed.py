@@ -7,8 +7,13 @@ rank 0 and replicated with one broadcast; every frame ends with one gather of th
 per-rank row buffers to rank 0, which scatters them back into frame order.  No other
 collective is involved.
 
-The pure index arithmetic lives in functions that do not need a GPU so that it can be tested
-with the gloo backend on CPU.
+Frames are pipelined two deep: the gather of frame i runs on the collective's own stream while
+the kernel of frame i+1 renders into the other row buffer; rank 0 restores frame order of frame
+i when frame i+1 has been enqueued (or at flush()).
+
+The index arithmetic and the pipelining logic do not need a GPU: ShardedRenderer takes the two
+device operations (render my tiles, restore frame order) as callables, so the same class runs
+under the gloo backend on CPU tensors in the tests.
 """
 import numpy as np
 
@@ -37,96 +42,122 @@ def assemble_rows_host(parts, height, tile_rows=TILE_ROWS):
     return frame
 
 
-def broadcast_bytes(buf, src=0, group=None):
+def broadcast_bytes(buf, device, src=0, group=None):
     """Broadcast a 1-D uint8 tensor whose length only `src` knows.  Returns the received tensor."""
     import torch
     import torch.distributed as dist
-    dev = buf.device if buf is not None else None
-    n = torch.tensor([0 if buf is None else buf.numel()], dtype=torch.int64)
-    if dist.get_backend(group) == "nccl":
-        n = n.cuda()
+    n = torch.tensor([0 if buf is None else buf.numel()], dtype=torch.int64, device=device)
     dist.broadcast(n, src=src, group=group)
-    size = int(n.item())
     if buf is None:
-        buf = torch.empty(size, dtype=torch.uint8, device=n.device if dev is None else dev)
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
     dist.broadcast(buf, src=src, group=group)
     return buf
 
 
 class ShardedRenderer:
-    """One rank of a multi-GPU render.  Rank 0 owns the scene description; every rank renders
-    its tiles; rank 0 ends up with the frame."""
+    """One rank of a multi-GPU render.  Every rank renders its tiles; rank 0 ends up with the frame.
 
-    def __init__(self, rt, device, scene=None, tile_rows=TILE_ROWS):
+    render_rows(frame_desc, rank, world, tile_rows, out[stride, W])   enqueue this rank's tiles
+    assemble(gathered[world, stride, W], frame_out[H, W], tile_rows)  restore frame order (rank 0)
+    stream_ctx()                                                      context manager entered around every enqueue
+    """
+
+    def __init__(self, device, render_rows, assemble, stream_ctx=None, tile_rows=TILE_ROWS):
+        import contextlib
         import torch
         import torch.distributed as dist
-        self.rt, self.torch, self.dist = rt, torch, dist
+        self.torch, self.dist = torch, dist
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.device = device
         self.tile_rows = tile_rows
-        self.device = torch.device("cuda", device)
-        torch.cuda.set_device(self.device)
-        rt.init(device)
-        self.ext_stream = torch.cuda.ExternalStream(rt.stream(), device=self.device)
-        self.bvh_info = None
-        self._blob = None
-        if self.rank == 0:
-            assert scene is not None, "rank 0 must be given the scene"
-            self.bvh_info = rt.upload_scene(scene)              # RayTracer::new on the owning rank
-        if self.world > 1:
-            if self.rank == 0:
-                _, nbytes = rt.scene_blob()
-                buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-                rt.copy_scene_blob(buf.data_ptr(), nbytes)
-            else:
-                buf = None
-            buf = self._bcast(buf)
-            if self.rank != 0:
-                torch.cuda.synchronize(self.device)
-                rt.adopt_scene_blob(buf.data_ptr(), buf.numel())
-                self._blob = buf                                 # keeps the adopted memory alive
+        self._render_rows, self._assemble = render_rows, assemble
+        self._stream_ctx = stream_ctx or contextlib.nullcontext
         self._bufs = {}
+        self._pending = None            # (work, slot, W, H) of the frame whose gather is in flight
+        self._slot = 0
 
-    def _bcast(self, buf):
-        torch, dist = self.torch, self.dist
-        n = torch.tensor([0 if buf is None else buf.numel()], dtype=torch.int64, device=self.device)
-        dist.broadcast(n, src=0)
-        if buf is None:
-            buf = torch.empty(int(n.item()), dtype=torch.uint8, device=self.device)
-        dist.broadcast(buf, src=0)
-        return buf
-
-    def _buffers(self, width, height):
+    def buffers(self, width, height):
         key = (width, height)
         if key not in self._bufs:
             torch = self.torch
             stride = max_shard_rows(height, self.world, self.tile_rows)
-            local = torch.zeros((stride, width), dtype=torch.int32, device=self.device)
-            gathered = frame = None
+            local = [torch.zeros((stride, width), dtype=torch.int32, device=self.device) for _ in range(2)]
+            gathered, frame = [None, None], None
             if self.rank == 0:
                 frame = torch.zeros((height, width), dtype=torch.int32, device=self.device)
                 if self.world > 1:
-                    gathered = torch.zeros((self.world, stride, width), dtype=torch.int32, device=self.device)
+                    gathered = [torch.zeros((self.world, stride, width), dtype=torch.int32, device=self.device) for _ in range(2)]
             self._bufs[key] = (stride, local, gathered, frame)
         return self._bufs[key]
 
+    def _complete(self):
+        """Rank 0: waits (on the stream, not the host) for the gather in flight and restores frame order."""
+        if self._pending is None:
+            return
+        work, slot, W, H = self._pending
+        self._pending = None
+        stride, local, gathered, frame = self.buffers(W, H)
+        work.wait()
+        if self.rank == 0:
+            self._assemble(gathered[slot], frame, self.tile_rows)
+
     def render_frame(self, frame_desc):
-        """Enqueues one frame on the library's stream.  On rank 0 returns the device tensor
-        [H, W] (int32 view of 0xFFRRGGBB) that will hold it once the stream has drained."""
-        rt, torch, dist = self.rt, self.torch, self.dist
+        """Enqueues one frame.  On rank 0 returns the tensor [H, W] (int32 view of 0xFFRRGGBB) that holds
+        the frame once flush() has been called (or one more frame has been enqueued) and the stream has drained."""
         W, H = frame_desc.width, frame_desc.height
-        stride, local, gathered, frame = self._buffers(W, H)
-        with torch.cuda.stream(self.ext_stream):
+        stride, local, gathered, frame = self.buffers(W, H)
+        with self._stream_ctx():
             if self.world == 1:
-                rt.render_tiles(frame_desc, 0, 1, frame.data_ptr(), tile_rows=self.tile_rows)
+                self._render_rows(frame_desc, 0, 1, self.tile_rows, frame)
                 return frame
-            rt.render_tiles(frame_desc, self.rank, self.world, local.data_ptr(), tile_rows=self.tile_rows)
-            dist.gather(local, list(gathered.unbind(0)) if self.rank == 0 else None, dst=0)
-            if self.rank == 0:
-                rt.assemble_tiles(gathered.data_ptr(), stride, self.world, W, H, frame.data_ptr(), tile_rows=self.tile_rows)
+            slot = self._slot
+            self._slot ^= 1
+            # the buffers of `slot` were last used two frames ago; that frame was completed one frame ago
+            self._render_rows(frame_desc, self.rank, self.world, self.tile_rows, local[slot])
+            work = self.dist.gather(local[slot], list(gathered[slot].unbind(0)) if self.rank == 0 else None, dst=0, async_op=True)
+            self._complete()                      # previous frame: its gather overlapped this frame's kernel launch
+            self._pending = (work, slot, W, H)
         return frame
 
-    def frame_to_host(self, frame):
-        self.rt.synchronize()
-        self.torch.cuda.synchronize(self.device)
-        return frame.cpu().numpy().view(np.uint32)
+    def flush(self):
+        with self._stream_ctx():
+            self._complete()
+
+
+def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS):
+    """ShardedRenderer on one MI355X: uploads (rank 0) or receives (other ranks) the scene and wires the
+    library's tile rendering and frame assembly in.  Returns (renderer, bvh_info or None)."""
+    import torch
+    import torch.distributed as dist
+    device = torch.device("cuda", device_index)
+    torch.cuda.set_device(device)
+    rt.init(device_index)
+    ext = torch.cuda.ExternalStream(rt.stream(), device=device)       # torch work is ordered on the library's stream
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    info, keep = None, None
+    if rank == 0:
+        assert scene is not None, "rank 0 must be given the scene"
+        info = rt.upload_scene(scene)                                  # RayTracer::new on the owning rank
+    if world > 1:
+        buf = None
+        if rank == 0:
+            _, nbytes = rt.scene_blob()
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            rt.copy_scene_blob(buf.data_ptr(), nbytes)
+        buf = broadcast_bytes(buf, device, src=0)
+        if rank != 0:
+            torch.cuda.synchronize(device)
+            rt.adopt_scene_blob(buf.data_ptr(), buf.numel())
+            keep = buf                                                 # the adopted memory must outlive the renderer
+
+    def render_rows(frame_desc, shard, nshards, rows, out):
+        rt.render_tiles(frame_desc, shard, nshards, out.data_ptr(), tile_rows=rows)
+
+    def assemble(gathered, frame, rows):
+        rt.assemble_tiles(gathered.data_ptr(), gathered.shape[1], gathered.shape[0], frame.shape[1], frame.shape[0], frame.data_ptr(), tile_rows=rows)
+
+    r = ShardedRenderer(device, render_rows, assemble, stream_ctx=lambda: torch.cuda.stream(ext), tile_rows=tile_rows)
+    r.ext_stream, r._keep_blob = ext, keep
+    return r, info

@@ -43,7 +43,7 @@ def _worker(rank, world, port, width, height, tile_rows, out_path):
             cfg = rt.ParsedConfigState().load_config_file(scene_path)
             host_blob, _ = rt.pack_scene_host(cfg.scene())
             blob = torch.from_numpy(host_blob.copy())
-        blob = shard.broadcast_bytes(blob, src=0)
+        blob = shard.broadcast_bytes(blob, torch.device("cpu"), src=0)
         # every rank checks that it received a well-formed blob of the announced size
         magic, version, total = np.frombuffer(blob.numpy()[:16].tobytes(), dtype=np.uint32)[0], \
             np.frombuffer(blob.numpy()[:16].tobytes(), dtype=np.uint32)[1], np.frombuffer(blob.numpy()[8:16].tobytes(), dtype=np.uint64)[0]
@@ -52,16 +52,40 @@ def _worker(rank, world, port, width, height, tile_rows, out_path):
         rows = shard.shard_row_indices(height, rank, world, tile_rows)
         assert len(rows) == rt.shard_rows(height, rank, world, tile_rows)
         sc = O.OracleScene.load(scene_path)
-        mine, _ = sc.render_tiles(rank, world, tile_rows, width=width, height=height, threads=2)
-        stride = shard.max_shard_rows(height, world, tile_rows)
-        local = torch.zeros((stride, width), dtype=torch.int32)
-        local[:len(rows)] = torch.from_numpy(mine.view(np.int32))
-        gathered = [torch.zeros_like(local) for _ in range(world)] if rank == 0 else None
-        dist.gather(local, gathered, dst=0)
+
+        # The renderer class the GPU benchmark uses, with the two device operations replaced by CPU
+        # stand-ins (rows from the oracle, numpy reassembly): pipelining, buffers and collectives are the same code.
+        def render_rows(frame_desc, shard_id, nshards, trows, out):
+            px, _ = sc.render_tiles(shard_id, nshards, trows, width=frame_desc.width, height=frame_desc.height, threads=2)
+            out.zero_()
+            out[:px.shape[0]] = torch.from_numpy(px.view(np.int32))
+
+        def assemble(gathered, frame, trows):
+            parts = [g.numpy().view(np.uint32) for g in gathered.unbind(0)]
+            frame.copy_(torch.from_numpy(shard.assemble_rows_host(parts, frame.shape[0], trows).view(np.int32)))
+
+        class FrameDesc:
+            pass
+
+        renderer = shard.ShardedRenderer(torch.device("cpu"), render_rows, assemble, tile_rows=tile_rows)
+        results = []
+        sizes = [(width, height), (width, height), (width // 2, height)]       # three frames through the two-deep pipeline
+        for w, h in sizes:
+            fd = FrameDesc()
+            fd.width, fd.height = w, h
+            out = renderer.render_frame(fd)
+            renderer.flush() if (w, h) != (width, height) else None
+            if rank == 0 and (w, h) != (width, height):
+                results.append((w, h, out.numpy().view(np.uint32).copy()))
+        renderer.flush()
         if rank == 0:
-            frame = shard.assemble_rows_host([g.numpy().view(np.uint32) for g in gathered], height, tile_rows)
+            full = renderer.buffers(width, height)[3].numpy().view(np.uint32)
             want, _ = sc.render(width=width, height=height, threads=2)
-            np.save(out_path, np.array([int(np.array_equal(frame, want))]))
+            ok = np.array_equal(full, want)
+            for w, h, got in results:
+                want2, _ = sc.render(width=w, height=h, threads=2)
+                ok = ok and np.array_equal(got, want2)
+            np.save(out_path, np.array([int(ok)]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
