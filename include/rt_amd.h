@@ -83,6 +83,9 @@ typedef struct rt_stats {
     uint64_t secondary;      /* reflection rays actually spawned          raytracer.rs:192  */
     uint64_t nodes_visited;  /* bounding boxes tested (32 bytes each)                       */
     uint64_t prims_tested;   /* exact shape tests (48 bytes each)                           */
+    uint64_t box_passes;     /* instrumented runs: wavefront-level passes of the box-test loop; lane use =
+                                nodes_visited / 2 / (64 * box_passes)                                   */
+    uint64_t shape_passes;   /* the same for the shape-test loop: prims_tested / (64 * shape_passes)  */
     double kernel_ms;        /* render kernel(s), HIP events on the library's stream        */
     double total_ms;         /* whole call, host clock                                      */
 } rt_stats;

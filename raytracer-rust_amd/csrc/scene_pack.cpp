@@ -120,7 +120,10 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
     // Boxes of the tree shapes (shape.rs:208-234).
     size_t nt = tree_in.size();
     std::vector<float> lo(3 * nt), hi(3 * nt);
-    for (size_t j = 0; j < nt; j++) {
+    bool finite_boxes = true;
+#pragma omp parallel for schedule(static) reduction(&& : finite_boxes) if (nt > 100000)
+    for (int64_t jj = 0; jj < (int64_t)nt; jj++) {
+        const size_t j = (size_t)jj;
         const Flat& f = tree_in[j]; size_t i = f.idx_in_kind;
         for (int k = 0; k < 3; k++) {
             if (f.kind == rtl::KIND_SPHERE) {
@@ -131,9 +134,10 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
                 lo[3 * j + k] = std::min(std::min(a, b), c);
                 hi[3 * j + k] = std::max(std::max(a, b), c);
             }
-            if (!std::isfinite(lo[3 * j + k]) || !std::isfinite(hi[3 * j + k])) { *err = "rt_scene: non-finite shape coordinates"; return false; }
+            if (!std::isfinite(lo[3 * j + k]) || !std::isfinite(hi[3 * j + k])) finite_boxes = false;
         }
     }
+    if (!finite_boxes) { *err = "rt_scene: non-finite shape coordinates"; return false; }
     // Absolute padding: a few parts per million of the extent that holds the bulk of the shapes
     // (5th..95th percentile of the box centres, so one huge ground sphere does not set the scale).
     float pad_abs = 0.0f;
@@ -197,15 +201,12 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
     blob->assign(off, 0);
     // Quantise the (already padded) builder boxes outwards onto the 16-bit scene grid.
     {
+        // The two children of the root bound everything below them.
         double glo[3] = {0, 0, 0}, ghi[3] = {0, 0, 0};
-        bool first = true;
-        for (const rtl::NodePair& p : bvh.pairs)
-            for (int c = 0; c < 2; c++)
-                for (int k = 0; k < 3; k++) {
-                    if (first) { glo[k] = p.c[c].lo[k]; ghi[k] = p.c[c].hi[k]; }
-                    else { glo[k] = std::min<double>(glo[k], p.c[c].lo[k]); ghi[k] = std::max<double>(ghi[k], p.c[c].hi[k]); }
-                    if (c == 1 && k == 2) first = false;
-                }
+        if (!bvh.pairs.empty() && !(bvh.root_ref & rtl::REF_LEAF)) {
+            const rtl::NodePair& p = bvh.pairs[bvh.root_ref];
+            for (int k = 0; k < 3; k++) { glo[k] = std::min(p.c[0].lo[k], p.c[1].lo[k]); ghi[k] = std::max(p.c[0].hi[k], p.c[1].hi[k]); }
+        }
         for (int k = 0; k < 3; k++) {
             h.grid_origin[k] = std::nextafter((float)glo[k], -INFINITY);
             float sc = (float)((ghi[k] - (double)h.grid_origin[k]) / (double)rtl::GRID_STEPS);

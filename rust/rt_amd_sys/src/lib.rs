@@ -54,6 +54,8 @@ pub struct rt_stats {
     pub secondary: u64,
     pub nodes_visited: u64,
     pub prims_tested: u64,
+    pub box_passes: u64,
+    pub shape_passes: u64,
     pub kernel_ms: f64,
     pub total_ms: f64,
 }

@@ -18,4 +18,6 @@ for md in (1, 2, 3, 4, 5):
         ts.append(s["kernel_ms"])
     rays = st["primary"] + st["shadow"] + st["secondary"]
     print(f"maxdepth {md}: kernel {min(ts):.3f} ms  rays {rays/1e6:.2f}M (p {st['primary']/1e6:.2f} s {st['shadow']/1e6:.2f} r {st['secondary']/1e6:.2f}) "
-          f"boxes {st['nodes_visited']/1e6:.1f}M shapes {st['prims_tested']/1e6:.1f}M  {rays/min(ts)/1e3:.0f} Mrays/s")
+          f"boxes {st['nodes_visited']/1e6:.1f}M shapes {st['prims_tested']/1e6:.1f}M  {rays/min(ts)/1e3:.0f} Mrays/s  "
+          f"lane use: box loop {st['nodes_visited'] / 2 / (64 * max(st['box_passes'], 1)):.3f} ({st['box_passes']/1e6:.1f}M passes), "
+          f"shape loop {st['prims_tested'] / (64 * max(st['shape_passes'], 1)):.3f} ({st['shape_passes']/1e6:.1f}M passes)")
