@@ -120,6 +120,14 @@ int rt_scene_blob(void** device_ptr, size_t* bytes);
 int rt_copy_scene_blob(void* device_dst, size_t bytes);   /* device-to-device copy of the blob, waits for completion */
 int rt_adopt_scene_blob(void* device_ptr, size_t bytes);
 
+/* RayTracer::new from a scene that was laid out earlier (rth_pack_scene, or a cache file read
+ * with rth_scene_cache_open): skips the tree build the reference repeats on every start
+ * (Bvh::build_par, raytracer.rs:32).  The blob is checked in full before it reaches the GPU
+ * (sections, every node and shape reference, tree shape), so a damaged file gives an error. */
+int rt_upload_scene_blob(const void* host_blob, size_t bytes);
+/* The resident blob copied to host memory (bytes as reported by rt_scene_blob), e.g. to write a cache. */
+int rt_download_scene_blob(void* host_dst, size_t bytes);
+
 /* RayTracer::render (raytracer.rs:40-79): renders the whole frame into host memory,
  * out_pixels[width * height].  `stats` may be NULL; when `count_work` is non-zero the
  * instrumented kernel also fills nodes_visited / prims_tested / shadow / secondary

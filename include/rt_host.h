@@ -55,6 +55,25 @@ int rth_image_compare(const uint32_t* a, uint32_t wa, uint32_t ha, const uint32_
  * tests without a GPU.  Free with rth_free. */
 int rth_pack_scene(const rt_scene* scene, void** blob, size_t* bytes, rt_bvh_info* info);
 void rth_free(void* p);
+/* The check rt_upload_scene_blob applies before a blob reaches the GPU: 0 when every section,
+ * node and shape reference is in range and the tree is a tree no deeper than the traversal stack. */
+int rth_validate_blob(const void* blob, size_t bytes);
+
+/* Binary scene cache.  The reference parses the text and rebuilds its tree on every start
+ * (main.rs:9-11, raytracer.rs:29-38); for a 10-million-triangle scene that is seconds of work
+ * against milliseconds of rendering.  One cache file holds the Config fields the render loop
+ * reads (config_builder.rs:14-24 without the shapes), the identity (size, modification time) of
+ * the scene file it was made from, and the device blob ready for rt_upload_scene_blob.
+ *   write:  parse, rth_pack_scene (or rt_upload_scene + rt_download_scene_blob), rth_scene_cache_write
+ *   read:   rth_scene_cache_open (maps the file, checks header and checksum), rth_scene_cache_is_fresh,
+ *           rt_upload_scene_blob(rth_scene_cache_blob(..)), rth_scene_cache_config for rth_config_frame */
+typedef struct rth_scene_cache rth_scene_cache;
+int rth_scene_cache_write(const char* path, const rth_config* c, const void* blob, size_t bytes, const char* source_path);
+rth_scene_cache* rth_scene_cache_open(const char* path);                       /* NULL on failure */
+const void* rth_scene_cache_blob(const rth_scene_cache* h, size_t* bytes);     /* valid until close */
+rth_config* rth_scene_cache_config(const rth_scene_cache* h);                  /* settings only, no shapes; rth_config_free */
+int rth_scene_cache_is_fresh(const rth_scene_cache* h, const char* source_path);   /* 1 when source_path is the file it was made from, unchanged */
+void rth_scene_cache_close(rth_scene_cache* h);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,8 @@ _SIGNATURES = {
     "rt_scene_blob": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "rt_copy_scene_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rt_adopt_scene_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rt_upload_scene_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rt_download_scene_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rt_render": (C.c_int, [C.POINTER(rt_frame), C.c_void_p, C.POINTER(rt_stats), C.c_int]),
     "rt_render_tiles": (C.c_int, [C.POINTER(rt_frame), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(rt_stats), C.c_int]),
     "rt_shard_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -100,6 +102,13 @@ _SIGNATURES = {
     "rth_image_compare": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]),
     "rth_pack_scene": (C.c_int, [C.POINTER(rt_scene), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(rt_bvh_info)]),
     "rth_free": (None, [C.c_void_p]),
+    "rth_validate_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rth_scene_cache_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p]),
+    "rth_scene_cache_open": (C.c_void_p, [C.c_char_p]),
+    "rth_scene_cache_blob": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "rth_scene_cache_config": (C.c_void_p, [C.c_void_p]),
+    "rth_scene_cache_is_fresh": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rth_scene_cache_close": (None, [C.c_void_p]),
 }
 
 _lib = None
@@ -275,6 +284,12 @@ def pack_scene_host(scene):
     return out, info.as_dict()
 
 
+def validate_blob(blob):
+    """Raises RtError unless `blob` (np.uint8 array) is a well-formed scene blob."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    _check(lib().rth_validate_blob(blob.ctypes.data, blob.size))
+
+
 # ------------------------------------------------------------------------------------ images
 class Image:
     """Image of imgcomparator/mod.rs:21-40: width, height, packed 0x??RRGGBB pixels."""
@@ -353,6 +368,70 @@ def adopt_scene_blob(device_ptr, nbytes):
     _check(lib().rt_adopt_scene_blob(C.c_void_p(device_ptr), nbytes))
 
 
+def upload_scene_blob(blob):
+    """A packed scene (np.uint8 array from pack_scene_host, or a SceneCache) -> resident scene; no tree build."""
+    if isinstance(blob, SceneCache):
+        ptr, n = blob.blob_pointer()
+    else:
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        ptr, n = blob.ctypes.data, blob.size
+    _check(lib().rt_upload_scene_blob(C.c_void_p(ptr), n))
+    info = rt_bvh_info()
+    _check(lib().rt_get_bvh_info(C.byref(info)))
+    return info.as_dict()
+
+
+def download_scene_blob():
+    """The resident scene blob as a np.uint8 array."""
+    _, n = scene_blob()
+    out = np.empty(n, dtype=np.uint8)
+    _check(lib().rt_download_scene_blob(out.ctypes.data, n))
+    return out
+
+
+class SceneCache:
+    """A binary scene cache file, memory-mapped (see rt_host.h)."""
+
+    def __init__(self, path):
+        h = lib().rth_scene_cache_open(os.fsencode(path))
+        if not h:
+            raise RtError(lib().rt_last_error().decode(errors="replace"))
+        self._h = h
+
+    @staticmethod
+    def write(path, config, blob, source_path=None):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        _check(lib().rth_scene_cache_write(os.fsencode(path), config._h, blob.ctypes.data, blob.size,
+                                           os.fsencode(source_path) if source_path else None))
+
+    def blob_pointer(self):
+        n = C.c_size_t()
+        p = lib().rth_scene_cache_blob(self._h, C.byref(n))
+        if not p:
+            raise RtError(lib().rt_last_error().decode(errors="replace"))
+        return p, n.value
+
+    def blob(self):
+        p, n = self.blob_pointer()
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+
+    def config(self):
+        h = lib().rth_scene_cache_config(self._h)
+        if not h:
+            raise RtError(lib().rt_last_error().decode(errors="replace"))
+        return Config(h)
+
+    def is_fresh(self, source_path):
+        return bool(lib().rth_scene_cache_is_fresh(self._h, os.fsencode(source_path)))
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rth_scene_cache_close(self._h)
+        self._h = None
+
+    __del__ = close
+
+
 def shard_rows(height, shard, nshards, tile_rows=TILE_ROWS):
     return int(lib().rt_shard_rows(height, shard, nshards, tile_rows))
 
@@ -399,6 +478,36 @@ class RayTracer:
     @classmethod
     def new(cls, config):
         return cls(config)
+
+    @classmethod
+    def from_scene_file(cls, path, cache_path=None, device=None):
+        """main.rs:9-11 with a binary cache beside the scene file: the first start parses the text,
+        builds the tree and writes `cache_path` (default: path + ".rtcache"); later starts map the
+        cache and upload it, as long as the scene file is unchanged."""
+        if _bound_device is None:
+            init(0 if device is None else device)
+        cache_path = cache_path or (os.fspath(path) + ".rtcache")
+        self = cls.__new__(cls)
+        self.last_stats = None
+        try:
+            cache = SceneCache(cache_path)
+        except RtError:
+            cache = None
+        if cache is not None and cache.is_fresh(path):
+            self.config = cache.config()
+            self._scene = None
+            self.bvh_info = upload_scene_blob(cache)
+            self.from_cache = True
+            cache.close()
+            return self
+        if cache is not None:
+            cache.close()
+        self.config = ParsedConfigState().load_config_file(path)
+        self._scene = self.config.scene()
+        self.bvh_info = upload_scene(self._scene)
+        SceneCache.write(cache_path, self.config, download_scene_blob(), source_path=path)
+        self.from_cache = False
+        return self
 
     def render(self, count_work=False):
         pixels, self.last_stats = render(self.config.frame(), count_work=count_work)

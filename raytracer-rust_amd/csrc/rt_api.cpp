@@ -195,6 +195,32 @@ int rt_upload_scene(const rt_scene* scene) {
     return 0;
 }
 
+int rt_upload_scene_blob(const void* host_blob, size_t bytes) {
+    if (!g.inited) return fail("rt_init has not been called");
+    std::string err;
+    if (!rtp::validate_blob((const uint8_t*)host_blob, bytes, &err)) return fail(err);
+    rtl::BlobHeader h; std::memcpy(&h, host_blob, sizeof(h));
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    release_scene();
+    HIP_TRY(hipMalloc(&g.d_blob, bytes));
+    g.blob_owned = true; g.blob_bytes = bytes;
+    HIP_TRY(hipMemcpyAsync(g.d_blob, host_blob, bytes, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    g.info = rt_bvh_info{};
+    point_at_blob(g.d_blob, h);
+    return 0;
+}
+
+int rt_download_scene_blob(void* host_dst, size_t bytes) {
+    if (!g.have_scene) return fail("no scene uploaded");
+    if (!host_dst || bytes != g.blob_bytes) return fail("rt_download_scene_blob: destination must be exactly the blob size");
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipMemcpyAsync(host_dst, g.d_blob, bytes, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
 int rt_get_bvh_info(rt_bvh_info* out) {
     if (!g.have_scene) return fail("no scene uploaded");
     if (!out) return fail("rt_bvh_info is NULL");

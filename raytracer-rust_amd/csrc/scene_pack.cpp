@@ -72,6 +72,57 @@ bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err) {
     return true;
 }
 
+// Full check of a blob that comes from outside the builder (a cache file): beyond the header,
+// every reference the kernels follow must stay inside its array and the tree must be a tree
+// (every pair reached exactly once, no deeper than the traversal stack), so that a damaged file
+// yields an error instead of a GPU fault or an endless traversal.
+bool validate_blob(const uint8_t* blob, size_t bytes, std::string* err) {
+    if (!blob || bytes < sizeof(rtl::BlobHeader)) { *err = "scene blob: smaller than its header"; return false; }
+    rtl::BlobHeader h; std::memcpy(&h, blob, sizeof(h));
+    if (!validate_header(h, bytes, err)) return false;
+    for (int k = 0; k < 3; k++)
+        if (!std::isfinite(h.grid_origin[k]) || !std::isfinite(h.grid_scale[k])) { *err = "scene blob: node grid is not finite"; return false; }
+    auto check_shapes = [&](uint64_t off, uint32_t n) {
+        const rtl::ShapeRec* r = (const rtl::ShapeRec*)(blob + off);
+        bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok) if (n > 100000)
+        for (int64_t i = 0; i < (int64_t)n; i++) ok = ok && (r[i].kind_mat & 3u) <= rtl::KIND_PLANE && (r[i].kind_mat >> 2) < h.n_materials;
+        return ok;
+    };
+    if (!check_shapes(h.off_tree_shapes, h.n_tree_shapes) || !check_shapes(h.off_list_shapes, h.n_list_shapes)) {
+        *err = "scene blob: shape with an unknown kind or material";
+        return false;
+    }
+    if (h.root_ref == rtl::REF_EMPTY || (h.root_ref & rtl::REF_LEAF)) {
+        if (h.n_pairs != 0) { *err = "scene blob: node pairs without a root"; return false; }
+        return true;
+    }
+    const rtl::QuantPair* pairs = (const rtl::QuantPair*)(blob + h.off_nodes);
+    std::vector<uint8_t> seen(h.n_pairs, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> stack;   // pair index, depth
+    stack.push_back({h.root_ref, 1});
+    uint64_t reached = 0;
+    while (!stack.empty()) {
+        auto [idx, depth] = stack.back(); stack.pop_back();
+        if (seen[idx]) { *err = "scene blob: node pair referenced twice"; return false; }
+        seen[idx] = 1; reached++;
+        if (depth > h.max_depth || depth > TREE_DEPTH_LIMIT) { *err = "scene blob: tree deeper than its header says"; return false; }
+        for (int c = 0; c < 2; c++) {
+            uint32_t ref = pairs[idx].c[c].ref;
+            if (ref == rtl::REF_EMPTY) continue;
+            if (ref & rtl::REF_LEAF) {
+                uint32_t first = (ref & ~rtl::REF_LEAF) >> 3, cnt = (ref & 7u) + 1u;
+                if ((uint64_t)first + cnt > h.n_tree_shapes) { *err = "scene blob: leaf outside the shape array"; return false; }
+            } else {
+                if (ref >= h.n_pairs) { *err = "scene blob: child outside the node array"; return false; }
+                stack.push_back({ref, depth + 1});
+            }
+        }
+    }
+    if (reached != h.n_pairs) { *err = "scene blob: unreachable node pairs"; return false; }
+    return true;
+}
+
 bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info, std::string* err) {
     auto t0 = std::chrono::steady_clock::now();
     if ((s.ntri && (!s.tri_v0 || !s.tri_v1 || !s.tri_v2 || !s.tri_mat)) || (s.nsph && (!s.sph_center || !s.sph_radius || !s.sph_mat)) ||

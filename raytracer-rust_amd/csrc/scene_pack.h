@@ -23,5 +23,9 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
 // Checks a blob header copied back from the device before the kernels are pointed at it.
 bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err);
 
+// Checks a whole blob in host memory that did not come from pack_scene in this process (a cache
+// file): header, every reference, tree shape.
+bool validate_blob(const uint8_t* blob, size_t bytes, std::string* err);
+
 }  // namespace rtp
 #endif

@@ -207,6 +207,48 @@ def test_scene_blob_round_trip_replicates_the_scene():
     rt.adopt_scene_blob(copy.data_ptr(), nbytes)      # leave a valid scene behind
 
 
+def test_scene_uploaded_as_a_blob_or_from_a_cache_file_renders_the_same_frame(tmp_path):
+    import shutil
+    src = str(tmp_path / "dragon.scene")
+    shutil.copy(os.path.join(GOLDEN, "final_avec_bonus.scene"), src)
+    gold = rt.file_to_image(os.path.join(GOLDEN, "dragon3.png"))
+    first = rt.RayTracer.from_scene_file(src)                      # parses, builds, writes the cache
+    assert not first.from_cache and os.path.exists(src + ".rtcache")
+    a = first.render()
+    second = rt.RayTracer.from_scene_file(src)                     # maps the cache, no parse, no build
+    assert second.from_cache and second.get_output_path() == "dragon3.png"
+    assert second.bvh_info["node_pairs"] == first.bvh_info["node_pairs"] and second.bvh_info["build_ms"] == 0
+    b = second.render()
+    assert np.array_equal(a.pixels(), b.pixels())
+    assert rt.Image.compare(b, gold)[0] == 0 and np.array_equal(b.pixels() & 0xFFFFFF, gold.pixels())
+    # host-built blob, uploaded directly
+    cfg = rt.ParsedConfigState().load_config_file(src)
+    blob, _ = rt.pack_scene_host(cfg.scene())
+    rt.upload_scene_blob(blob)
+    c, _ = rt.render(cfg.frame())
+    assert np.array_equal(c & 0xFFFFFF, gold.pixels())
+    assert np.array_equal(rt.download_scene_blob(), blob)
+    # a changed scene file invalidates the cache
+    with open(src, "a") as f:
+        f.write("sphere 0 5 -1 2\n")
+    third = rt.RayTracer.from_scene_file(src)
+    assert not third.from_cache
+    assert not np.array_equal(third.render().pixels() & 0xFFFFFF, gold.pixels())
+
+
+def test_damaged_blob_is_refused_and_the_resident_scene_survives():
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
+    tracer = rt.RayTracer.new(cfg)
+    before = tracer.render().pixels()
+    blob, _ = rt.pack_scene_host(cfg.scene())
+    bad = blob.copy()
+    hdr_nodes = int(np.frombuffer(bad[16:24].tobytes(), np.uint64)[0])
+    bad[hdr_nodes + 12:hdr_nodes + 16] = np.frombuffer(np.uint32(0x7FFFFFF0).tobytes(), np.uint8)   # first child -> far outside
+    with pytest.raises(rt.RtError, match="scene blob"):
+        rt.upload_scene_blob(bad)
+    assert np.array_equal(tracer.render().pixels(), before)
+
+
 def test_errors_are_reported_not_fatal():
     cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "test_file", "jalon3", "tp31.test"))
     rt.RayTracer.new(cfg)

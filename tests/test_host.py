@@ -138,10 +138,8 @@ ALL_SCENES = sorted(glob.glob(os.path.join(GOLDEN, "test_file", "*", "*.test")))
     os.path.join(GOLDEN, "test.scene"), os.path.join(GOLDEN, "final_avec_bonus.scene")]
 
 
-@pytest.mark.parametrize("path", ALL_SCENES, ids=[os.path.basename(p) for p in ALL_SCENES])
-def test_flattened_scene_equals_oracle_parse(path):
-    cfg = rt.ParsedConfigState().load_config_file(path)
-    shapes, lights, cam = _flatten_from_oracle(path)
+def _assert_same_scene(cfg, oracle_scene):
+    shapes, lights, cam = oracle_scene.export()
     s = cfg.scene()
     kinds = shapes[:, 0].astype(int)
     tri, sph, pl = shapes[kinds == 1], shapes[kinds == 0], shapes[kinds == 2]
@@ -150,21 +148,119 @@ def test_flattened_scene_equals_oracle_parse(path):
     def arr(p, n, k):
         return np.ctypeslib.as_array(p, shape=(n, k)) if n else np.zeros((0, k), np.float32)
 
-    assert np.array_equal(arr(s.tri_v0, s.ntri, 3), tri[:, 1:4]) and np.array_equal(arr(s.tri_v1, s.ntri, 3), tri[:, 4:7])
-    assert np.array_equal(arr(s.tri_v2, s.ntri, 3), tri[:, 7:10]) and np.array_equal(arr(s.tri_mat, s.ntri, 7), tri[:, 10:17])
-    assert np.array_equal(arr(s.sph_center, s.nsph, 3), sph[:, 1:4]) and np.array_equal(arr(s.sph_radius, s.nsph, 1)[:, 0], sph[:, 4])
-    assert np.array_equal(arr(s.sph_mat, s.nsph, 7), sph[:, 10:17])
-    assert np.array_equal(arr(s.pl_point, s.npl, 3), pl[:, 1:4]) and np.array_equal(arr(s.pl_normal, s.npl, 3), pl[:, 4:7])
-    assert np.array_equal(arr(s.lights, s.nlights, 7), lights)
+    def same(a, b):       # bit patterns, so that NaN == NaN
+        return np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32), np.ascontiguousarray(b, np.float32).view(np.uint32))
+
+    assert same(arr(s.tri_v0, s.ntri, 3), tri[:, 1:4]) and same(arr(s.tri_v1, s.ntri, 3), tri[:, 4:7])
+    assert same(arr(s.tri_v2, s.ntri, 3), tri[:, 7:10]) and same(arr(s.tri_mat, s.ntri, 7), tri[:, 10:17])
+    assert same(arr(s.sph_center, s.nsph, 3), sph[:, 1:4]) and same(arr(s.sph_radius, s.nsph, 1)[:, 0], sph[:, 4])
+    assert same(arr(s.sph_mat, s.nsph, 7), sph[:, 10:17])
+    assert same(arr(s.pl_point, s.npl, 3), pl[:, 1:4]) and same(arr(s.pl_normal, s.npl, 3), pl[:, 4:7])
+    assert same(arr(s.pl_mat, s.npl, 7), pl[:, 10:17])
+    assert same(arr(s.lights, s.nlights, 7), lights)
     order = np.concatenate([np.ctypeslib.as_array(p, shape=(n,)) if n else np.zeros(0, np.uint32)
                             for p, n in ((s.tri_order, s.ntri), (s.sph_order, s.nsph), (s.pl_order, s.npl))])
     file_pos = np.concatenate([np.nonzero(kinds == 1)[0], np.nonzero(kinds == 0)[0], np.nonzero(kinds == 2)[0]])
     assert np.array_equal(order, file_pos)
     # frame constants (raytracer.rs:46-55) agree bit for bit with the oracle's
     f = cfg.frame()
-    want = O.OracleScene.load(path).frame_setup()
+    want = oracle_scene.frame_setup()
     got = np.float32(list(f.pos) + list(f.cv) + list(f.right) + list(f.up) + [f.pixel_w, f.pixel_h, f.half_w, f.half_h])
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    i = oracle_scene.info()
+    assert (f.width, f.height, f.maxdepth) == (i["width"], i["height"], i["maxdepth"])
+
+
+@pytest.mark.parametrize("path", ALL_SCENES, ids=[os.path.basename(p) for p in ALL_SCENES])
+def test_flattened_scene_equals_oracle_parse(path):
+    _assert_same_scene(rt.ParsedConfigState().load_config_file(path), O.OracleScene.load(path))
+
+
+def _big_scene_text(seed, lines=160_000):
+    """A few MiB of scene text (the parser works in chunks of 1 MiB) with every kind of line
+    scattered through it, so that vertex numbering, the current material, ambient and maxverts
+    all have to be carried across chunk borders."""
+    rng = np.random.default_rng(seed)
+    out = ["size 320 200", "camera 0 -30 12 0 0 0 0 0 1 50", "maxdepth 3", "maxverts 1000", "ambient 0.1 0.1 0.1"]
+    nverts, maxverts = 0, 1000
+    for i in range(lines):
+        r = rng.random()
+        if r < 0.45 and nverts < maxverts:
+            x, y, z = rng.uniform(-20, 20, 3)
+            out.append(f"vertex {float(x)!r} {y:.6e} {z:.3f}")
+            nverts += 1
+        elif r < 0.80 and nverts >= 3:
+            a, b, c = rng.integers(0, nverts, 3)
+            out.append(f"tri {a} {b} +{c}")
+        elif r < 0.84:
+            x, y, z, rad = rng.uniform(-20, 20, 3).tolist() + [rng.uniform(0.1, 2)]
+            out.append(f"sphere {x:.4f} {y:.4f} {z:.4f} {rad:.4f}")
+        elif r < 0.88:
+            d = rng.uniform(0, 0.8, 3)
+            out.append(f"diffuse {d[0]:.3f} {d[1]:.3f} {d[2]:.3f}")
+        elif r < 0.91:
+            d = rng.uniform(0, 1, 3)
+            out.append(f"specular {d[0]:.3f} {d[1]:.3f} {d[2]:.3f}")
+        elif r < 0.93:
+            out.append(f"shininess {rng.integers(0, 50)}")
+        elif r < 0.94:
+            out.append("# a comment line\r")
+        elif r < 0.945:
+            n = rng.uniform(-1, 1, 3)
+            out.append(f"plane 0 0 {rng.uniform(-30, -20):.2f} {n[0]:.3f} {n[1]:.3f} {abs(n[2]) + 0.1:.3f}")
+        elif r < 0.95:
+            out.append(f"directional {rng.uniform(-1, 1):.3f} 0.5 1 0.2 0.2 0.2" if rng.random() < 0.5 else f"point {rng.uniform(-30, 30):.3f} 10 40 .3 .3 .3")
+        elif r < 0.955:
+            maxverts += 500
+            out.append(f"maxverts {maxverts}")
+        elif r < 0.956:
+            out.append("ambient 0.1 0.15 0.2")
+        else:
+            out.append("")
+    return "\n".join(out) + "\n"
+
+
+def test_multi_chunk_text_equals_oracle_parse(tmp_path):
+    text = _big_scene_text(1)
+    assert len(text) > 3 << 20
+    _assert_same_scene(_parse(text), O.OracleScene.parse(text))
+    path = tmp_path / "big.scene"                  # and through the memory-mapped file route
+    path.write_text(text)
+    _assert_same_scene(rt.ParsedConfigState().load_config_file(str(path)), O.OracleScene.parse(text))
+
+
+@pytest.mark.parametrize("first,second,msg", [
+    ("tri 0 1 99999999", "bogus 1 2", "Triangle vertex index out of bounds"),
+    ("bogus 1 2", "tri 0 1 99999999", "Unknown configuration key: bogus"),
+    ("diffuse 0.95 0 0", "sphere 0 0 0", "Sum of diffuse color and ambient light components must not exceed 1.0"),
+    ("sphere 0 0 0 -1", "diffuse 0.95 0 0", "Sphere radius must be greater than zero"),
+    ("tri 0 1 18446744073709551616", "vertex 0 0", "number too large to fit in target type"),
+])
+def test_earliest_failing_line_wins_across_chunks(first, second, msg):
+    text = _big_scene_text(2, lines=120_000)
+    lines = text.split("\n")
+    lines.insert(len(lines) // 3, first)           # lands in an earlier chunk than `second`
+    lines.insert(2 * len(lines) // 3, second)
+    bad = "\n".join(lines)
+    with pytest.raises(rt.RtError) as e:
+        _parse(bad)
+    assert str(e.value) == msg
+    with pytest.raises(ValueError) as e2:
+        O.OracleScene.parse(bad)
+    assert str(e2.value) == msg
+
+
+def test_vertex_pool_limit_is_checked_where_the_line_stands():
+    text = "maxverts 2\n" + "#" * (2 << 20) + "\nvertex 0 0 0\nvertex 1 0 0\nvertex 2 0 0\nmaxverts 10\n"
+    with pytest.raises(rt.RtError, match="Exceeded maximum number of vertices"):
+        _parse(text)
+    ok = "maxverts 2\nvertex 0 0 0\n" + "#" * (2 << 20) + "\nvertex 1 0 0\nmaxverts 3\nvertex 2 0 0\ntri 0 1 2\n"
+    assert _parse(ok).scene().ntri == 1
+
+
+def test_missing_file_reports_the_os_error():
+    with pytest.raises(rt.RtError, match=r"No such file or directory \(os error 2\)"):
+        rt.ParsedConfigState().load_config_file("/nonexistent/x.scene")
 
 
 # ------------------------------------------------------------------ comparator twin
@@ -323,6 +419,110 @@ def test_depth_limit_holds_on_adversarial_input():
 
 
 # ------------------------------------------------------------------ sharding arithmetic
+# ------------------------------------------------------------------ blob validation and the scene cache file
+def _dragon_blob():
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
+    blob, _ = rt.pack_scene_host(cfg.scene())
+    return cfg, blob
+
+
+def test_builder_output_passes_the_blob_check():
+    for name in ("final_avec_bonus.scene", "test.scene", os.path.join("test_file", "jalon5", "tp55.test")):
+        cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, name))
+        blob, _ = rt.pack_scene_host(cfg.scene())
+        rt.validate_blob(blob)
+
+
+@pytest.mark.parametrize("damage,msg", [
+    ("child_out_of_range", "child outside the node array"),
+    ("cycle", "node pair referenced twice"),
+    ("leaf_out_of_range", "leaf outside the shape array"),
+    ("material", "unknown kind or material"),
+    ("truncated", "size does not match its header"),
+    ("magic", "bad magic or version"),
+    ("orphan", "unreachable node pairs"),
+])
+def test_damaged_blobs_are_rejected_before_they_reach_a_gpu(damage, msg):
+    _, blob = _dragon_blob()
+    blob = blob.copy()
+    b = _read_blob(blob)
+    nodes = b["nodes"]                       # views into `blob`: [lo/hi words x3, ref] per child
+    inner = [i for i in range(len(nodes)) if not (nodes[i, 3] & 0x80000000)]
+    if damage == "child_out_of_range":
+        nodes[inner[0], 3] = len(nodes) + 5
+    elif damage == "cycle":
+        nodes[inner[5], 3] = b["root"]
+    elif damage == "leaf_out_of_range":
+        leafy = next(i for i in range(len(nodes)) if nodes[i, 3] & 0x80000000 and nodes[i, 3] != 0xFFFFFFFF)
+        nodes[leafy, 3] = 0x80000000 | ((len(b["tree"]) - 1) << 3) | 7
+    elif damage == "material":
+        b["tree"][10, 3] = 1 | (b["n_mat"] << 2)
+    elif damage == "truncated":
+        blob = blob[:-256]
+    elif damage == "magic":
+        blob[0] ^= 0xFF
+    elif damage == "orphan":
+        nodes[inner[0], 3] = 0xFFFFFFFF      # drops a whole subtree
+    with pytest.raises(rt.RtError, match=msg):
+        rt.validate_blob(blob)
+
+
+def test_scene_cache_round_trip(tmp_path):
+    src = os.path.join(GOLDEN, "final_avec_bonus.scene")
+    cfg, blob = _dragon_blob()
+    path = str(tmp_path / "dragon.rtcache")
+    rt.SceneCache.write(path, cfg, blob, source_path=src)
+    cache = rt.SceneCache(path)
+    assert np.array_equal(cache.blob(), blob)
+    c2 = cache.config()
+    assert (c2.width, c2.height, c2.maxdepth, c2.output_file) == (cfg.width, cfg.height, cfg.maxdepth, cfg.output_file)
+    assert c2.camera == cfg.camera and c2.ambient == cfg.ambient
+    f1, f2 = cfg.frame(), c2.frame()
+    assert bytes(f1) == bytes(f2)
+    assert cache.is_fresh(src) and not cache.is_fresh(os.path.join(GOLDEN, "test.scene")) and not cache.is_fresh(str(tmp_path / "none"))
+    cache.close()
+
+
+def test_scene_cache_goes_stale_when_the_scene_file_changes(tmp_path):
+    scene = tmp_path / "s.scene"
+    scene.write_text("size 8 8\nsphere 0 0 5 1\n")
+    cfg = rt.ParsedConfigState().load_config_file(str(scene))
+    blob, _ = rt.pack_scene_host(cfg.scene())
+    path = str(tmp_path / "s.rtcache")
+    rt.SceneCache.write(path, cfg, blob, source_path=str(scene))
+    assert rt.SceneCache(path).is_fresh(str(scene))
+    scene.write_text("size 8 8\nsphere 0 0 5 1.5\n")
+    os.utime(scene, ns=(1, 1))
+    assert not rt.SceneCache(path).is_fresh(str(scene))
+
+
+@pytest.mark.parametrize("damage,msg", [("flip", "checksum mismatch"), ("truncate", "truncated"), ("magic", "not a cache file"),
+                                        ("short", "not a cache file"), ("version", "another version")])
+def test_damaged_cache_files_are_rejected(tmp_path, damage, msg):
+    cfg, blob = _dragon_blob()
+    path = tmp_path / "d.rtcache"
+    rt.SceneCache.write(str(path), cfg, blob)
+    raw = bytearray(path.read_bytes())
+    if damage == "flip":
+        raw[4096 + len(blob) // 2] ^= 1
+    elif damage == "truncate":
+        raw = raw[:-64]
+    elif damage == "magic":
+        raw[0] ^= 0xFF
+    elif damage == "short":
+        raw = raw[:100]
+    elif damage == "version":
+        raw[8] += 1
+    path.write_bytes(bytes(raw))
+    with pytest.raises(rt.RtError, match=msg):
+        rt.SceneCache(str(path))
+
+
+def test_missing_cache_file_is_an_error():
+    with pytest.raises(rt.RtError, match="os error 2"):
+        rt.SceneCache("/nonexistent/x.rtcache")
+
+
 @pytest.mark.parametrize("height,nshards,tile", [(480, 1, 8), (2160, 8, 8), (2161, 8, 8), (7, 4, 8), (100, 3, 16), (4320, 8, 8)])
 def test_shard_rows_partition_the_frame(height, nshards, tile):
     rows = [rt.shard_rows(height, s, nshards, tile) for s in range(nshards)]
