@@ -149,6 +149,17 @@ uint32_t rt_shard_rows(uint32_t height, uint32_t shard, uint32_t nshards, uint32
 int rt_assemble_tiles(const uint32_t* d_gathered, uint32_t rows_per_shard_stride, uint32_t nshards,
                       uint32_t tile_rows, uint32_t width, uint32_t height, uint32_t* d_frame);
 
+/* Image::compare (src/imgcomparator/mod.rs:54-89) on two frames in device memory: *count = number of
+ * pixels with a colour channel differing by more than 1; d_diff (may be NULL) receives the difference
+ * image (dr << 16 | dg << 8 | db for those pixels, 0 elsewhere).  Different dimensions are the
+ * reference's error "Images have different dimensions".  Buffers 16-byte aligned.  Waits for the result. */
+int rt_compare_frames(const uint32_t* d_a, uint32_t width_a, uint32_t height_a, const uint32_t* d_b, uint32_t width_b, uint32_t height_b,
+                      uint32_t* d_diff, uint64_t* count);
+
+/* The per-pixel loop of save_image (src/imgcomparator/mod.rs:156-162) on the device: 0x??RRGGBB words to
+ * R,G,B byte triples (3 * width * height bytes) for a PNG encoder.  Asynchronous on rt_stream(). */
+int rt_pack_rgb(const uint32_t* d_pixels, uint32_t width, uint32_t height, uint8_t* d_rgb);
+
 /* The HIP stream (hipStream_t) the library launches on, for callers that order their own
  * device work or events against it. */
 void* rt_stream(void);

@@ -59,6 +59,14 @@ void rth_free(void* p);
  * node and shape reference is in range and the tree is a tree no deeper than the traversal stack. */
 int rth_validate_blob(const void* blob, size_t bytes);
 
+/* PNG files.  save_image (src/imgcomparator/mod.rs:150-166): 0x??RRGGBB pixels (or R,G,B bytes as
+ * rt_pack_rgb produces them) to an 8-bit RGB PNG, rows compressed in parallel.  file_to_image
+ * (mod.rs:128-148): any non-interlaced 8/16-bit PNG to 0x00RRGGBB pixels (alpha dropped);
+ * *pixels is released with rth_free. */
+int rth_save_png(const char* path, const uint32_t* pixels, uint32_t width, uint32_t height);
+int rth_save_png_rgb(const char* path, const uint8_t* rgb, uint32_t width, uint32_t height);
+int rth_load_png(const char* path, uint32_t** pixels, uint32_t* width, uint32_t* height);
+
 /* Binary scene cache.  The reference parses the text and rebuilds its tree on every start
  * (main.rs:9-11, raytracer.rs:29-38); for a 10-million-triangle scene that is seconds of work
  * against milliseconds of rendering.  One cache file holds the Config fields the render loop

@@ -87,6 +87,8 @@ _SIGNATURES = {
     "rt_render_tiles": (C.c_int, [C.POINTER(rt_frame), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(rt_stats), C.c_int]),
     "rt_shard_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rt_assemble_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rt_compare_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rt_pack_rgb": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "rt_stream": (C.c_void_p, []),
     "rt_synchronize": (C.c_int, []),
     "rt_last_error": (C.c_char_p, []),
@@ -103,6 +105,9 @@ _SIGNATURES = {
     "rth_pack_scene": (C.c_int, [C.POINTER(rt_scene), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(rt_bvh_info)]),
     "rth_free": (None, [C.c_void_p]),
     "rth_validate_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rth_save_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rth_save_png_rgb": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rth_load_png": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rth_scene_cache_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p]),
     "rth_scene_cache_open": (C.c_void_p, [C.c_char_p]),
     "rth_scene_cache_blob": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
@@ -317,16 +322,26 @@ def extract_rgb(pixel):
 
 
 def file_to_image(path):
-    from PIL import Image as PILImage
-    im = np.asarray(PILImage.open(path).convert("RGB"), dtype=np.uint32)
-    return Image(im.shape[1], im.shape[0], (im[..., 0] << 16) | (im[..., 1] << 8) | im[..., 2])
+    """file_to_image of imgcomparator/mod.rs:128-148: a PNG as 0x00RRGGBB pixels."""
+    p, w, h = C.c_void_p(), C.c_uint32(), C.c_uint32()
+    _check(lib().rth_load_png(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)))
+    try:
+        data = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(w.value * h.value,)).copy()
+    finally:
+        lib().rth_free(p)
+    return Image(w.value, h.value, data)
 
 
 def save_image(img, path):
-    from PIL import Image as PILImage
-    p = img.pixels()
-    rgb = np.stack([(p >> 16) & 0xFF, (p >> 8) & 0xFF, p & 0xFF], axis=-1).astype(np.uint8)
-    PILImage.fromarray(rgb, "RGB").save(path)
+    """save_image of imgcomparator/mod.rs:150-166: 8-bit RGB PNG."""
+    _check(lib().rth_save_png(os.fsencode(path), img.data.ctypes.data, img.width, img.height))
+
+
+def save_image_rgb(rgb, width, height, path):
+    """The same from R,G,B bytes (what pack_rgb leaves in device memory, copied to the host)."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    assert rgb.size == 3 * width * height
+    _check(lib().rth_save_png_rgb(os.fsencode(path), rgb.ctypes.data, width, height))
 
 
 # ------------------------------------------------------------------------------------ renderer
@@ -454,6 +469,19 @@ def render_tiles(frame, shard, nshards, device_ptr, tile_rows=TILE_ROWS, want_st
 
 def assemble_tiles(gathered_ptr, stride_rows, nshards, width, height, frame_ptr, tile_rows=TILE_ROWS):
     _check(lib().rt_assemble_tiles(C.c_void_p(gathered_ptr), stride_rows, nshards, tile_rows, width, height, C.c_void_p(frame_ptr)))
+
+
+def compare_frames(ptr_a, size_a, ptr_b, size_b, diff_ptr=None):
+    """Image::compare on two frames in device memory; sizes are (width, height).  Returns the count."""
+    count = C.c_uint64()
+    _check(lib().rt_compare_frames(C.c_void_p(ptr_a), size_a[0], size_a[1], C.c_void_p(ptr_b), size_b[0], size_b[1],
+                                   C.c_void_p(diff_ptr) if diff_ptr else None, C.byref(count)))
+    return int(count.value)
+
+
+def pack_rgb(pixels_ptr, width, height, rgb_ptr):
+    """0x??RRGGBB words -> R,G,B bytes, device to device, asynchronous on stream()."""
+    _check(lib().rt_pack_rgb(C.c_void_p(pixels_ptr), width, height, C.c_void_p(rgb_ptr)))
 
 
 def synchronize():

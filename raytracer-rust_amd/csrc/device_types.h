@@ -30,5 +30,9 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
                                         unsigned long long* d_counters, int stack_depth, int count, hipStream_t stream);
 extern "C" hipError_t rtk_launch_assemble(const uint32_t* d_gathered, uint32_t stride_rows, uint32_t nshards, uint32_t tile_rows,
                                           uint32_t width, uint32_t height, uint32_t* d_frame, hipStream_t stream);
+// image_kernels.hip; pointers must be 16-byte aligned (d_rgb: 4-byte).
+extern "C" hipError_t rtk_launch_compare(const uint32_t* d_a, const uint32_t* d_b, size_t n, uint32_t* d_diff, unsigned long long* d_count,
+                                         hipStream_t stream);
+extern "C" hipError_t rtk_launch_pack_rgb(const uint32_t* d_pixels, size_t n, uint8_t* d_rgb, hipStream_t stream);
 
 #endif

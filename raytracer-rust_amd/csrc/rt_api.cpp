@@ -313,6 +313,31 @@ int rt_assemble_tiles(const uint32_t* d_gathered, uint32_t rows_per_shard_stride
     return 0;
 }
 
+int rt_compare_frames(const uint32_t* d_a, uint32_t width_a, uint32_t height_a, const uint32_t* d_b, uint32_t width_b, uint32_t height_b,
+                      uint32_t* d_diff, uint64_t* count) {
+    if (!g.inited) return fail("rt_init has not been called");
+    if (height_a != height_b || width_a != width_b) return fail("Images have different dimensions");            // mod.rs:55-57
+    if (!d_a || !d_b) return fail("rt_compare_frames: NULL image");
+    if (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)d_diff) & 15u) return fail("rt_compare_frames: buffers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipMemsetAsync(g.d_counters, 0, sizeof(unsigned long long), g.stream));
+    HIP_TRY(rtk_launch_compare(d_a, d_b, (size_t)width_a * height_a, d_diff, g.d_counters, g.stream));
+    unsigned long long c = 0;
+    HIP_TRY(hipMemcpyAsync(&c, g.d_counters, sizeof(c), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (count) *count = c;
+    return 0;
+}
+
+int rt_pack_rgb(const uint32_t* d_pixels, uint32_t width, uint32_t height, uint8_t* d_rgb) {
+    if (!g.inited) return fail("rt_init has not been called");
+    if (!d_pixels || !d_rgb) return fail("rt_pack_rgb: NULL buffer");
+    if (((uintptr_t)d_pixels & 15u) || ((uintptr_t)d_rgb & 3u)) return fail("rt_pack_rgb: pixels must be 16-byte and rgb 4-byte aligned");
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(rtk_launch_pack_rgb(d_pixels, (size_t)width * height, d_rgb, g.stream));
+    return 0;
+}
+
 void* rt_stream(void) { return (void*)g.stream; }
 
 int rt_synchronize(void) {

@@ -249,6 +249,69 @@ def test_damaged_blob_is_refused_and_the_resident_scene_survives():
     assert np.array_equal(tracer.render().pixels(), before)
 
 
+def _frames_on_device(rng, w, h):
+    import torch
+    a = rng.integers(0, 1 << 32, size=(h, w), dtype=np.uint32)
+    b = a.copy()
+    n = a.size
+    # a third untouched, a third nudged by one in some channel (tolerated), a third changed freely
+    idx = rng.permutation(n)
+    flat = b.reshape(-1)
+    for j in idx[: n // 3]:
+        ch = 8 * int(rng.integers(0, 3))
+        v = (int(flat[j]) >> ch) & 0xFF
+        flat[j] = (int(flat[j]) & ~(0xFF << ch)) | (min(v + 1, 255) << ch)
+    flat[idx[n // 3: 2 * n // 3]] = rng.integers(0, 1 << 32, size=len(idx[n // 3: 2 * n // 3]), dtype=np.uint32)
+    ta = torch.from_numpy(a.view(np.int32)).to("cuda:0")
+    tb = torch.from_numpy(b.view(np.int32)).to("cuda:0")
+    return a, b, ta, tb
+
+
+@pytest.mark.parametrize("size", [(1, 1), (3, 1), (64, 64), (333, 7), (1921, 1081)])
+def test_device_compare_equals_image_compare(size):
+    import torch
+    w, h = size
+    a, b, ta, tb = _frames_on_device(np.random.default_rng(w * 31 + h), w, h)
+    want_count, want_diff = rt.Image.compare(rt.Image(w, h, a), rt.Image(w, h, b))      # host twin of mod.rs:54-89
+    td = torch.full((h, w), -1, dtype=torch.int32, device="cuda:0")
+    got = rt.compare_frames(ta.data_ptr(), (w, h), tb.data_ptr(), (w, h), td.data_ptr())
+    assert got == want_count
+    assert np.array_equal(td.cpu().numpy().view(np.uint32).reshape(-1), want_diff.data)
+    assert rt.compare_frames(ta.data_ptr(), (w, h), tb.data_ptr(), (w, h)) == want_count     # without a difference image
+    assert rt.compare_frames(ta.data_ptr(), (w, h), ta.data_ptr(), (w, h)) == 0
+    with pytest.raises(rt.RtError, match="Images have different dimensions"):
+        rt.compare_frames(ta.data_ptr(), (w, h), tb.data_ptr(), (h, w + 1))
+
+
+def test_device_compare_of_a_render_against_its_golden_image():
+    import torch
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
+    rt.RayTracer.new(cfg)
+    frame = cfg.frame()
+    out = torch.zeros((frame.height, frame.width), dtype=torch.int32, device="cuda:0")
+    rt.render_tiles(frame, 0, 1, out.data_ptr())
+    gold = rt.file_to_image(os.path.join(GOLDEN, "dragon3.png"))
+    tg = torch.from_numpy(gold.pixels().view(np.int32)).to("cuda:0")
+    assert rt.compare_frames(out.data_ptr(), (frame.width, frame.height), tg.data_ptr(), (gold.width, gold.height)) == 0
+
+
+@pytest.mark.parametrize("size", [(1, 1), (5, 3), (640, 480), (1001, 11)])
+def test_device_rgb_packing_feeds_the_png_writer(size, tmp_path):
+    import torch
+    w, h = size
+    px = np.random.default_rng(w).integers(0, 1 << 32, size=(h, w), dtype=np.uint32)
+    tp = torch.from_numpy(px.view(np.int32)).to("cuda:0")
+    rgb = torch.zeros(3 * w * h + 8, dtype=torch.uint8, device="cuda:0")
+    rt.pack_rgb(tp.data_ptr(), w, h, rgb.data_ptr())
+    rt.synchronize()
+    got = rgb.cpu().numpy()
+    want = np.stack([(px >> 16) & 0xFF, (px >> 8) & 0xFF, px & 0xFF], axis=-1).astype(np.uint8).reshape(-1)
+    assert np.array_equal(got[:3 * w * h], want) and not got[3 * w * h:].any()
+    path = str(tmp_path / "f.png")
+    rt.save_image_rgb(got[:3 * w * h], w, h, path)
+    assert np.array_equal(rt.file_to_image(path).pixels(), px & 0xFFFFFF)
+
+
 def test_errors_are_reported_not_fatal():
     cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "test_file", "jalon3", "tp31.test"))
     rt.RayTracer.new(cfg)

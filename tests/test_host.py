@@ -419,6 +419,70 @@ def test_depth_limit_holds_on_adversarial_input():
 
 
 # ------------------------------------------------------------------ sharding arithmetic
+# ------------------------------------------------------------------ PNG files
+@pytest.mark.parametrize("size", [(1, 1), (7, 5), (640, 480), (2000, 1500)])
+def test_png_round_trip_and_independent_decoder(size, tmp_path):
+    from PIL import Image as PILImage
+    w, h = size
+    rng = np.random.default_rng(w + h)
+    px = rng.integers(0, 1 << 32, size=(h, w), dtype=np.uint32)
+    if w > 1000:                              # smooth content, several bands of rows
+        yy, xx = np.mgrid[0:h, 0:w]
+        px = (((xx * 255 // w) << 16) | ((yy * 255 // h) << 8) | ((xx ^ yy) & 0xFF)).astype(np.uint32)
+    path = str(tmp_path / "a.png")
+    rt.save_image(rt.Image(w, h, px), path)
+    back = rt.file_to_image(path)
+    assert (back.width, back.height) == (w, h) and np.array_equal(back.pixels(), px & 0xFFFFFF)
+    pil = np.asarray(PILImage.open(path).convert("RGB"), dtype=np.uint32)       # written file is a valid PNG for others
+    assert np.array_equal((pil[..., 0] << 16) | (pil[..., 1] << 8) | pil[..., 2], px & 0xFFFFFF)
+
+
+@pytest.mark.parametrize("mode", ["L", "LA", "RGB", "RGBA", "P", "I;16"])
+def test_png_reader_handles_every_colour_type(mode, tmp_path):
+    from PIL import Image as PILImage
+    rng = np.random.default_rng(5)
+    w, h = 37, 23
+    if mode == "I;16":
+        im = PILImage.fromarray(rng.integers(0, 1 << 16, size=(h, w), dtype=np.uint16))
+        want_rgb = np.asarray(im, dtype=np.uint32) >> 8
+        want = (want_rgb << 16) | (want_rgb << 8) | want_rgb
+    else:
+        base = PILImage.fromarray(rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8), "RGBA")
+        im = base.convert(mode) if mode != "P" else base.convert("RGB").quantize(64)
+        rgb = np.asarray(im.convert("RGB"), dtype=np.uint32)
+        want = (rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2]
+    path = str(tmp_path / "m.png")
+    im.save(path)
+    assert np.array_equal(rt.file_to_image(path).pixels(), want)
+
+
+def test_png_reader_matches_pil_on_every_fixture():
+    from PIL import Image as PILImage
+    files = glob.glob(os.path.join(GOLDEN, "**", "*.png"), recursive=True)
+    assert len(files) >= 23
+    for f in files:
+        ref = np.asarray(PILImage.open(f).convert("RGB"), dtype=np.uint32)
+        assert np.array_equal(rt.file_to_image(f).pixels(), (ref[..., 0] << 16) | (ref[..., 1] << 8) | ref[..., 2]), f
+
+
+def test_png_errors(tmp_path):
+    with pytest.raises(rt.RtError, match="os error 2"):
+        rt.file_to_image("/nonexistent/a.png")
+    p = tmp_path / "x.png"
+    p.write_bytes(b"not a png at all")
+    with pytest.raises(rt.RtError, match="not a PNG file"):
+        rt.file_to_image(str(p))
+    good = tmp_path / "g.png"
+    rt.save_image(rt.Image(4, 4, np.arange(16)), str(good))
+    raw = bytearray(good.read_bytes())
+    raw[40] ^= 0x55
+    p.write_bytes(bytes(raw))
+    with pytest.raises(rt.RtError, match="PNG"):
+        rt.file_to_image(str(p))
+    with pytest.raises(rt.RtError):
+        rt.save_image(rt.Image(4, 4, np.arange(16)), "/nonexistent/dir/a.png")
+
+
 # ------------------------------------------------------------------ blob validation and the scene cache file
 def _dragon_blob():
     cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
