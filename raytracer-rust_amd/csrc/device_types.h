@@ -24,6 +24,10 @@ struct DevFrame {
     uint32_t width, height, maxdepth;
     float ambient[3];
     uint32_t shard, nshards, tile_rows, local_rows;
+    // Pixel-tile order of the launch.  region_log2 == 0: block b renders tile b in row-major order.
+    // Otherwise the frame is cut into square regions of (1 << region_log2)^2 tiles and the blocks
+    // that share an XCD (b, b + 8, b + 16, ...) walk through one region after another.
+    uint32_t region_log2, regions_x, n_regions;
 };
 
 extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, uint32_t* d_out, float4* d_fold,

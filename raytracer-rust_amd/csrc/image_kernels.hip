@@ -47,9 +47,15 @@ __global__ __launch_bounds__(256) void compare_kernel(const uint32_t* __restrict
         mine += (uint32_t)d0;
         if (diff) diff[i] = d;
     }
-    // One atomic per wavefront.
+    // One atomic per block: every update of the one counter word is serialised in L2.
+    __shared__ uint32_t per_wave[4];
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(count, (unsigned long long)mine);
+    if ((threadIdx.x & 63u) == 0) per_wave[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = per_wave[0] + per_wave[1] + per_wave[2] + per_wave[3];
+        if (total) atomicAdd(count, (unsigned long long)total);
+    }
 }
 
 __global__ __launch_bounds__(256) void pack_rgb_kernel(const uint32_t* __restrict__ pixels, size_t n, uint8_t* __restrict__ rgb) {
@@ -78,7 +84,7 @@ uint32_t streaming_blocks(size_t n) {
     // Enough 256-thread blocks for every CU to hold several, capped: the kernels stride over the rest.
     size_t want = ((n >> 2) + 255) / 256;
     if (want < 1) want = 1;
-    if (want > 256u * 32u) want = 256u * 32u;
+    if (want > 256u * 8u) want = 256u * 8u;
     return (uint32_t)want;
 }
 

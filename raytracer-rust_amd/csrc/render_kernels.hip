@@ -327,8 +327,22 @@ __global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, D
                                                     unsigned long long* __restrict__ counters) {
     __shared__ uint32_t s_stack[STACK * 64];
     const uint32_t lane = threadIdx.x;
-    const uint32_t tiles_x = (f.width + 7u) >> 3;
-    const uint32_t tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    // Which 8x8 pixel tile this wavefront renders.  Workgroups are dealt round-robin over the 8
+    // XCDs, each with an L2 of its own: in row-major order every XCD would touch every part of
+    // the scene.  For big frames the blocks of one XCD instead sweep a square region of tiles at a
+    // time, so that the rays in flight on an XCD share the nodes and shapes in its L2.
+    uint32_t tile_x, tile_y;
+    if (f.region_log2 == 0) {
+        const uint32_t tiles_x = (f.width + 7u) >> 3;
+        tile_x = blockIdx.x % tiles_x; tile_y = blockIdx.x / tiles_x;
+    } else {
+        const uint32_t per_log2 = 2u * f.region_log2, side_mask = (1u << f.region_log2) - 1u;
+        const uint32_t xcd_slot = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const uint32_t region = ((j >> per_log2) << 3) + xcd_slot, t = j & ((1u << per_log2) - 1u);
+        if (region >= f.n_regions) return;
+        const uint32_t rx = region % f.regions_x, ry = region / f.regions_x;
+        tile_x = (rx << f.region_log2) + (t & side_mask); tile_y = (ry << f.region_log2) + (t >> f.region_log2);
+    }
     const uint32_t x = tile_x * 8u + (lane & 7u), r = tile_y * 8u + (lane >> 3);
     uint32_t* stack = s_stack + lane;
     Counters cnt = {0u, 0u, 0u, 0u, 0u, 0u};
@@ -451,6 +465,18 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     uint32_t tiles_x = (f->width + 7u) >> 3, tiles_y = (f->local_rows + 7u) >> 3;
     uint64_t blocks = (uint64_t)tiles_x * tiles_y;
     if (blocks == 0) return hipSuccess;
+    DevFrame placed = *f;
+    placed.region_log2 = 0; placed.regions_x = 0; placed.n_regions = 0;
+    // Regions of 16x16 tiles (128x128 pixels) once the frame has enough tiles to keep all XCDs busy
+    // region by region; larger regions lose more to imbalance between XCDs than they gain in L2.
+    const uint32_t region_log2 = blocks >= (1u << 14) ? 4u : 0u;
+    if (region_log2 > 0) {
+        const uint32_t side = 1u << region_log2;
+        const uint32_t rx = (tiles_x + side - 1) / side, ry = (tiles_y + side - 1) / side;
+        placed.region_log2 = region_log2; placed.regions_x = rx; placed.n_regions = rx * ry;
+        blocks = (((uint64_t)rx * ry + 7u) / 8u) * 8u * side * side;
+    }
+    f = &placed;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((uint32_t)blocks), block(64);
     if (stack_depth <= 32) {
