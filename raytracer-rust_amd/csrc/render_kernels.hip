@@ -201,7 +201,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
     if (cur == REF_EMPTY) return;
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = best->prim == NO_PRIM ? INF : prune_limit(best->t);
-    uint32_t sp = 0;
+    uint32_t sp = 1;                                    // entry 0 of every lane's stack holds REF_EMPTY: popping needs no emptiness test
     // All lanes descend through inner nodes until each has reached a leaf (or run out of nodes),
     // then all test their leaves together.  A lane that reaches its leaf early sets it aside and
     // keeps descending towards its next one instead of idling (it then tests both).
@@ -221,17 +221,16 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
                 cur = swap ? r1 : r0;
             } else if (h0) cur = r0;
             else if (h1) cur = r1;
-            else if (sp == 0) cur = REF_EMPTY;
             else { sp--; cur = stack[sp * 64]; }
             if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {
                 held = cur;
-                if (sp == 0) cur = REF_EMPTY; else { sp--; cur = stack[sp * 64]; }
+                sp--; cur = stack[sp * 64];
             }
             if (!__any(held == 0 && !(cur & REF_LEAF))) break;    // nobody is still looking for a first leaf
         }
         if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf
             held = cur;
-            if (sp == 0) cur = REF_EMPTY; else { sp--; cur = stack[sp * 64]; }
+            sp--; cur = stack[sp * 64];
         }
         while (held != 0) {
             uint32_t first = (held & ~REF_LEAF) >> 3, count = (held & 7u) + 1u;
@@ -248,7 +247,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             held = 0;
             if ((cur & REF_LEAF) && cur != REF_EMPTY) {
                 held = cur;
-                if (sp == 0) cur = REF_EMPTY; else { sp--; cur = stack[sp * 64]; }
+                sp--; cur = stack[sp * 64];
             }
         }
         if (cur == REF_EMPTY) break;
@@ -277,7 +276,7 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
     if (cur == REF_EMPTY) return false;
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = point_light ? prune_limit(light_dist) : INF;
-    uint32_t sp = 0;
+    uint32_t sp = 1;
     while (cur != REF_EMPTY) {
         while (!(cur & REF_LEAF)) {
             const uint4* n = sc.nodes + 2 * (size_t)cur;
@@ -290,7 +289,6 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
             if (h0 && h1) { stack[sp * 64] = r1; sp++; cur = r0; }
             else if (h0) cur = r0;
             else if (h1) cur = r1;
-            else if (sp == 0) cur = REF_EMPTY;
             else { sp--; cur = stack[sp * 64]; }
         }
         if (cur != REF_EMPTY) {
@@ -300,8 +298,7 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
                 if (COUNT) { cnt->prims++; if (first_active_lane()) cnt->wave_prim_iters++; }
                 if (occludes(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
             }
-            if (sp == 0) cur = REF_EMPTY;
-            else { sp--; cur = stack[sp * 64]; }
+            sp--; cur = stack[sp * 64];
         }
     }
     return false;
@@ -345,6 +342,7 @@ __global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, D
     }
     const uint32_t x = tile_x * 8u + (lane & 7u), r = tile_y * 8u + (lane >> 3);
     uint32_t* stack = s_stack + lane;
+    stack[0] = REF_EMPTY;
     Counters cnt = {0u, 0u, 0u, 0u, 0u, 0u};
     const bool live = x < f.width && r < f.local_rows;
     if (live) {
@@ -479,7 +477,7 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     f = &placed;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((uint32_t)blocks), block(64);
-    if (stack_depth <= 32) {
+    if (stack_depth < 32) {   // one entry is the sentinel
         if (count) hipLaunchKernelGGL((render_kernel<32, true>), grid, block, 0, stream, *sc, *f, d_out, d_fold, d_counters);
         else hipLaunchKernelGGL((render_kernel<32, false>), grid, block, 0, stream, *sc, *f, d_out, d_fold, d_counters);
     } else {

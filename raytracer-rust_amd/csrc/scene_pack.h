@@ -15,8 +15,9 @@ namespace rtp {
 // every ray, straight from the list (the jalon3/5/6 scenes have at most 6).
 constexpr uint32_t SMALL_SCENE = 8;
 
-// Longest root-to-leaf path the builder may produce = deepest traversal stack a kernel offers.
-constexpr uint32_t TREE_DEPTH_LIMIT = 64;
+// Longest root-to-leaf path the builder may produce: the deepest traversal stack a kernel offers
+// (64 entries) less the sentinel entry at its bottom.
+constexpr uint32_t TREE_DEPTH_LIMIT = 63;
 
 bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info, std::string* err);
 
