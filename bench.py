@@ -79,6 +79,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Libraries underneath (RCCL prints a version banner) write to file descriptor 1; the contract is
+    # ONE JSON line on stdout, so everything else is sent to stderr and the line goes to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -89,8 +95,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if world > 1:
+    # RT_BENCH_REHEARSE_COLLECTIVES=1 sends a single rank through the RCCL broadcast / gather path of
+    # N > 1 as well (a rehearsal of that code on one GPU; never set for a reported number).
+    use_dist = world > 1 or bool(os.environ.get("RT_BENCH_REHEARSE_COLLECTIVES"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -103,11 +113,11 @@ def main():
         cfg = rt.ParsedConfigState().load_config_file(SCENE)
         cfg.set_size(args.width, args.height)
     t_up = time.perf_counter()
-    renderer, bvh_info = shard_mod.gpu_renderer(rt, local_rank, scene=cfg.scene() if rank == 0 else None)
+    renderer, bvh_info = shard_mod.gpu_renderer(rt, local_rank, scene=cfg.scene() if rank == 0 else None, always_gather=use_dist)
     upload_s = time.perf_counter() - t_up
 
     # Every rank needs the frame constants; they are 22 numbers, computed on the host (tanf).
-    if world > 1:
+    if use_dist:
         fr = torch.zeros(22, dtype=torch.float64, device=renderer.device)
         if rank == 0:
             f = cfg.frame()
@@ -127,19 +137,19 @@ def main():
     W, H = frame.width, frame.height
     # Work of this rank's shard (deterministic): instrumented kernel, outside the timed region.
     stride, local, gathered, full = renderer.buffers(W, H)
-    target = full if world == 1 else local[0]
+    target = local[0] if use_dist else full
     st = rt.render_tiles(frame, rank, world, target.data_ptr(), count_work=True)
     counts = torch.tensor([st["primary"], st["shadow"], st["secondary"], st["nodes_visited"], st["prims_tested"]],
                           dtype=torch.int64, device=renderer.device)
     mine = counts.clone()
-    if world > 1:
+    if use_dist:
         dist.all_reduce(counts)
     primary, shadow, secondary, nodes, prims = (int(x) for x in counts.cpu().tolist())
 
     def sync_all():
         rt.synchronize()
         torch.cuda.synchronize(renderer.device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(renderer.device)
 
@@ -158,7 +168,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=renderer.device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -211,9 +221,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ge.load_oracle(), W, H)
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=real_stdout, flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -62,7 +62,7 @@ class ShardedRenderer:
     stream_ctx()                                                      context manager entered around every enqueue
     """
 
-    def __init__(self, device, render_rows, assemble, stream_ctx=None, tile_rows=TILE_ROWS):
+    def __init__(self, device, render_rows, assemble, stream_ctx=None, tile_rows=TILE_ROWS, always_gather=False):
         import contextlib
         import torch
         import torch.distributed as dist
@@ -76,6 +76,9 @@ class ShardedRenderer:
         self._bufs = {}
         self._pending = None            # (work, slot, W, H) of the frame whose gather is in flight
         self._slot = 0
+        # A single rank normally renders straight into the frame; with always_gather it goes through
+        # the same gather and reassembly as many ranks do (to rehearse that path on one GPU).
+        self._collectives = self.world > 1 or (always_gather and dist.is_initialized())
 
     def buffers(self, width, height):
         key = (width, height)
@@ -86,7 +89,7 @@ class ShardedRenderer:
             gathered, frame = [None, None], None
             if self.rank == 0:
                 frame = torch.zeros((height, width), dtype=torch.int32, device=self.device)
-                if self.world > 1:
+                if self._collectives:
                     gathered = [torch.zeros((self.world, stride, width), dtype=torch.int32, device=self.device) for _ in range(2)]
             self._bufs[key] = (stride, local, gathered, frame)
         return self._bufs[key]
@@ -108,7 +111,7 @@ class ShardedRenderer:
         W, H = frame_desc.width, frame_desc.height
         stride, local, gathered, frame = self.buffers(W, H)
         with self._stream_ctx():
-            if self.world == 1:
+            if not self._collectives:
                 self._render_rows(frame_desc, 0, 1, self.tile_rows, frame)
                 return frame
             slot = self._slot
@@ -125,7 +128,7 @@ class ShardedRenderer:
             self._complete()
 
 
-def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS):
+def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gather=False):
     """ShardedRenderer on one MI355X: uploads (rank 0) or receives (other ranks) the scene and wires the
     library's tile rendering and frame assembly in.  Returns (renderer, bvh_info or None)."""
     import torch
@@ -140,7 +143,7 @@ def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS):
     if rank == 0:
         assert scene is not None, "rank 0 must be given the scene"
         info = rt.upload_scene(scene)                                  # RayTracer::new on the owning rank
-    if world > 1:
+    if world > 1 or (always_gather and dist.is_initialized()):
         buf = None
         if rank == 0:
             _, nbytes = rt.scene_blob()
@@ -158,6 +161,7 @@ def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS):
     def assemble(gathered, frame, rows):
         rt.assemble_tiles(gathered.data_ptr(), gathered.shape[1], gathered.shape[0], frame.shape[1], frame.shape[0], frame.data_ptr(), tile_rows=rows)
 
-    r = ShardedRenderer(device, render_rows, assemble, stream_ctx=lambda: torch.cuda.stream(ext), tile_rows=tile_rows)
+    r = ShardedRenderer(device, render_rows, assemble, stream_ctx=lambda: torch.cuda.stream(ext), tile_rows=tile_rows,
+                        always_gather=always_gather)
     r.ext_stream, r._keep_blob = ext, keep
     return r, info

@@ -312,6 +312,40 @@ def test_device_rgb_packing_feeds_the_png_writer(size, tmp_path):
     assert np.array_equal(rt.file_to_image(path).pixels(), px & 0xFFFFFF)
 
 
+def test_collective_path_on_a_single_rank_group():
+    """The broadcast / gather / reassembly path of a multi-GPU render, rehearsed with an RCCL group of
+    one rank: frames pipelined two deep must equal the plain render."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    shard_mod = importlib.import_module("raytracer_rust_amd.distributed")
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
+    cfg.set_size(801, 453)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        renderer, info = shard_mod.gpu_renderer(rt, 0, scene=cfg.scene(), always_gather=True)
+        want, _ = rt.render(cfg.frame())
+        frame = cfg.frame()
+        for _ in range(3):
+            out = renderer.render_frame(frame)
+        renderer.flush()
+        rt.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want)
+        small = cfg.frame()
+        small.width, small.height = 160, 90          # another frame size through the same renderer
+        want_small, _ = rt.render(small)
+        out = renderer.render_frame(small)
+        renderer.flush()
+        rt.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want_small)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_errors_are_reported_not_fatal():
     cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "test_file", "jalon3", "tp31.test"))
     rt.RayTracer.new(cfg)
