@@ -1,7 +1,8 @@
 //! Drop-in for the reference's `src/raytracer/` directory: flattens `Config` and hands the render
 //! loop to the MI355X library.  Add `mod gpu_render;` to `src/raytracer/mod.rs`, add
 //! `rt_amd_sys = { path = "<this repo>/rust/rt_amd_sys" }` to `Cargo.toml`, and call the two
-//! functions from `RayTracer::new` / `RayTracer::render` as INTEGRATION.md shows.
+//! functions from `RayTracer::new` (in place of the tree build, raytracer.rs:31-35) and
+//! `RayTracer::render` (in place of its body, raytracer.rs:41-78).
 //!
 //! Not compiled where it was written (no Rust toolchain there).
 use crate::imgcomparator::Image;
@@ -9,6 +10,7 @@ use crate::raytracer::config::light::Light;
 use crate::raytracer::config::shape::Shape;
 use crate::raytracer::config::Config;
 use rt_amd_sys as sys;
+use std::ffi::CString;
 use std::ptr;
 
 fn push3(v: &mut Vec<f32>, a: &nalgebra::Vector3<f32>) { v.extend_from_slice(&[a.x, a.y, a.z]); }
@@ -55,6 +57,39 @@ pub fn upload(config: &Config, device: i32) -> Result<(), String> {
     unsafe {
         sys::check(sys::rt_init(device))?;
         sys::check(sys::rt_upload_scene(&scene))
+    }
+}
+
+/// RayTracer::new for a scene whose laid-out form was cached in `cache_path` by an earlier run
+/// (`save_cache` below): maps the file, checks it, uploads it; no tree build.  `scene_path` is
+/// the text file the cache must still belong to (size and modification time).
+pub fn upload_from_cache(cache_path: &str, scene_path: &str, device: i32) -> Result<bool, String> {
+    let (cp, sp) = (CString::new(cache_path).map_err(|e| e.to_string())?, CString::new(scene_path).map_err(|e| e.to_string())?);
+    unsafe {
+        let cache = sys::rth_scene_cache_open(cp.as_ptr());
+        if cache.is_null() { return Ok(false); }                       // no cache yet (or a damaged one): build as usual
+        let fresh = sys::rth_scene_cache_is_fresh(cache, sp.as_ptr()) == 1;
+        let mut result = Ok(false);
+        if fresh {
+            let mut bytes: usize = 0;
+            let blob = sys::rth_scene_cache_blob(cache, &mut bytes);
+            result = sys::check(sys::rt_init(device)).and_then(|_| sys::check(sys::rt_upload_scene_blob(blob, bytes))).map(|_| true);
+        }
+        sys::rth_scene_cache_close(cache);
+        result
+    }
+}
+
+/// Writes the resident scene next to the scene file so that the next start can skip parse and build.
+/// `config_handle` is the C-side twin of the Config (rth_load_config_file), which carries the frame settings.
+pub fn save_cache(cache_path: &str, scene_path: &str, config_handle: *const sys::rth_config) -> Result<(), String> {
+    let (cp, sp) = (CString::new(cache_path).map_err(|e| e.to_string())?, CString::new(scene_path).map_err(|e| e.to_string())?);
+    unsafe {
+        let (mut dptr, mut bytes) = (ptr::null_mut(), 0usize);
+        sys::check(sys::rt_scene_blob(&mut dptr, &mut bytes))?;
+        let mut host = vec![0u8; bytes];
+        sys::check(sys::rt_download_scene_blob(host.as_mut_ptr() as *mut _, bytes))?;
+        sys::check(sys::rth_scene_cache_write(cp.as_ptr(), config_handle, host.as_ptr() as *const _, bytes, sp.as_ptr()))
     }
 }
 

@@ -1,4 +1,4 @@
-//! Raw bindings to `include/rt_amd.h` plus a thin safe layer.
+//! Raw bindings to `include/rt_amd.h` (and the scene-cache part of `include/rt_host.h`) plus a thin safe layer.
 //!
 //! Not compiled where it was written (no Rust toolchain there); the declarations follow the C
 //! header field for field.  Every struct is `#[repr(C)]` plain data.
@@ -60,9 +60,31 @@ pub struct rt_stats {
     pub total_ms: f64,
 }
 
+/// Opaque handles of `include/rt_host.h`.
+#[repr(C)]
+pub struct rth_config { _private: [u8; 0] }
+#[repr(C)]
+pub struct rth_scene_cache { _private: [u8; 0] }
+
 extern "C" {
     pub fn rt_init(device: c_int) -> c_int;
     pub fn rt_upload_scene(scene: *const rt_scene) -> c_int;
+    pub fn rt_upload_scene_blob(host_blob: *const c_void, bytes: usize) -> c_int;
+    pub fn rt_download_scene_blob(host_dst: *mut c_void, bytes: usize) -> c_int;
+    pub fn rt_compare_frames(d_a: *const u32, width_a: u32, height_a: u32, d_b: *const u32, width_b: u32, height_b: u32,
+                             d_diff: *mut u32, count: *mut u64) -> c_int;
+    pub fn rt_pack_rgb(d_pixels: *const u32, width: u32, height: u32, d_rgb: *mut u8) -> c_int;
+    pub fn rt_assemble_tiles(d_gathered: *const u32, rows_per_shard_stride: u32, nshards: u32, tile_rows: u32, width: u32, height: u32,
+                             d_frame: *mut u32) -> c_int;
+    pub fn rt_stream() -> *mut c_void;
+    pub fn rth_load_config_file(path: *const c_char) -> *mut rth_config;
+    pub fn rth_config_free(c: *mut rth_config);
+    pub fn rth_scene_cache_write(path: *const c_char, c: *const rth_config, blob: *const c_void, bytes: usize, source_path: *const c_char) -> c_int;
+    pub fn rth_scene_cache_open(path: *const c_char) -> *mut rth_scene_cache;
+    pub fn rth_scene_cache_blob(h: *const rth_scene_cache, bytes: *mut usize) -> *const c_void;
+    pub fn rth_scene_cache_is_fresh(h: *const rth_scene_cache, source_path: *const c_char) -> c_int;
+    pub fn rth_scene_cache_close(h: *mut rth_scene_cache);
+    pub fn rth_save_png(path: *const c_char, pixels: *const u32, width: u32, height: u32) -> c_int;
     pub fn rt_render(frame: *const rt_frame, out_pixels: *mut u32, stats: *mut rt_stats, count_work: c_int) -> c_int;
     pub fn rt_render_tiles(frame: *const rt_frame, shard: u32, nshards: u32, tile_rows: u32, d_out: *mut u32,
                            stats: *mut rt_stats, count_work: c_int) -> c_int;
