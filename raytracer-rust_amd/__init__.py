@@ -77,6 +77,7 @@ _SIGNATURES = {
     "rt_frame_from_camera": (C.c_int, [_FP, _FP, _FP, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, _FP, C.POINTER(rt_frame)]),
     "rt_init": (C.c_int, [C.c_int]),
     "rt_upload_scene": (C.c_int, [C.POINTER(rt_scene)]),
+    "rt_upload_scene_ex": (C.c_int, [C.POINTER(rt_scene), C.c_uint32]),
     "rt_get_bvh_info": (C.c_int, [C.POINTER(rt_bvh_info)]),
     "rt_scene_blob": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "rt_copy_scene_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -362,8 +363,12 @@ def shutdown():
     _bound_device = None
 
 
-def upload_scene(scene):
-    _check(lib().rt_upload_scene(C.byref(scene)))
+BUILD_ON_GPU = 1
+
+
+def upload_scene(scene, gpu_build=False):
+    """RayTracer::new: tree build (host split search, or on the GPU with gpu_build=True) + upload."""
+    _check(lib().rt_upload_scene_ex(C.byref(scene), BUILD_ON_GPU if gpu_build else 0))
     info = rt_bvh_info()
     _check(lib().rt_get_bvh_info(C.byref(info)))
     return info.as_dict()
@@ -495,12 +500,12 @@ def stream():
 class RayTracer:
     """RayTracer of raytracer.rs:16-83 on one MI355X."""
 
-    def __init__(self, config, device=None):
+    def __init__(self, config, device=None, gpu_build=False):
         if _bound_device is None:
             init(0 if device is None else device)
         self.config = config
         self._scene = config.scene() if isinstance(config, Config) else config.c
-        self.bvh_info = upload_scene(self._scene)          # RayTracer::new builds the tree (raytracer.rs:32)
+        self.bvh_info = upload_scene(self._scene, gpu_build=gpu_build)          # RayTracer::new builds the tree (raytracer.rs:32)
         self.last_stats = None
 
     @classmethod

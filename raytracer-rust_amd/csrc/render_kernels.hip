@@ -319,10 +319,12 @@ __device__ __forceinline__ uint32_t frame_row(const DevFrame& f, uint32_t r) {
     return (lt * f.nshards + f.shard) * f.tile_rows + within;
 }
 
-template <int STACK, bool COUNT>
+// Traversal stacks, [entry][lane]: sized at launch for the tree at hand (its depth plus the sentinel entry).
+extern __shared__ uint32_t s_stack[];
+
+template <bool COUNT>
 __global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, DevFrame f, uint32_t* __restrict__ out, float4* __restrict__ fold,
                                                     unsigned long long* __restrict__ counters) {
-    __shared__ uint32_t s_stack[STACK * 64];
     const uint32_t lane = threadIdx.x;
     // Which 8x8 pixel tile this wavefront renders.  Workgroups are dealt round-robin over the 8
     // XCDs, each with an L2 of its own: in row-major order every XCD would touch every part of
@@ -477,13 +479,12 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     f = &placed;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((uint32_t)blocks), block(64);
-    if (stack_depth < 32) {   // one entry is the sentinel
-        if (count) hipLaunchKernelGGL((render_kernel<32, true>), grid, block, 0, stream, *sc, *f, d_out, d_fold, d_counters);
-        else hipLaunchKernelGGL((render_kernel<32, false>), grid, block, 0, stream, *sc, *f, d_out, d_fold, d_counters);
-    } else {
-        if (count) hipLaunchKernelGGL((render_kernel<64, true>), grid, block, 0, stream, *sc, *f, d_out, d_fold, d_counters);
-        else hipLaunchKernelGGL((render_kernel<64, false>), grid, block, 0, stream, *sc, *f, d_out, d_fold, d_counters);
-    }
+    // One stack entry per tree level plus the sentinel; 8 KiB (32 entries) still lets 5 wavefronts per SIMD fit.
+    const uint32_t entries = (uint32_t)(stack_depth < 7 ? 8 : stack_depth + 1);
+    if (entries > 64) return hipErrorInvalidValue;
+    const size_t lds_bytes = (size_t)entries * 64 * sizeof(uint32_t);
+    if (count) hipLaunchKernelGGL((render_kernel<true>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters);
+    else hipLaunchKernelGGL((render_kernel<false>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters);
     return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "bvh_gpu.h"
 #include "device_types.h"
 #include "errors.h"
 #include "layout.h"
@@ -192,6 +193,35 @@ int rt_upload_scene(const rt_scene* scene) {
     HIP_TRY(hipStreamSynchronize(g.stream));
     point_at_blob(g.d_blob, h);
     g.info = info;
+    return 0;
+}
+
+int rt_upload_scene_ex(const rt_scene* scene, uint32_t flags) {
+    if (!(flags & RT_BUILD_ON_GPU)) return rt_upload_scene(scene);
+    auto t0 = std::chrono::steady_clock::now();
+    if (!g.inited) return fail("rt_init has not been called");
+    if (!scene) return fail("rt_scene is NULL");
+    rtp::SceneParts parts; std::string err;
+    if (!rtp::split_scene(*scene, &parts, &err)) return fail(err);
+    if (!parts.use_tree || parts.tree.size() < 2) return rt_upload_scene(scene);       // nothing to build a tree over
+    rtg::SceneParts in{};
+    in.tree = parts.tree.data(); in.n_tree = (uint32_t)parts.tree.size();
+    in.list = parts.list.data(); in.n_list = (uint32_t)parts.list.size();
+    in.mats = parts.mats.data(); in.n_mats = (uint32_t)parts.mats.size();
+    in.lights = parts.lights.data(); in.n_lights = (uint32_t)parts.lights.size();
+    in.finite_shading = parts.finite_shading; in.pad_abs = parts.pad_abs; in.depth_limit = rtp::TREE_DEPTH_LIMIT;
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    rtg::BuiltScene built{};
+    rtg::BuildStatus st = rtg::build_scene_on_gpu(in, g.stream, &built, &err);
+    if (st == rtg::BUILD_TOO_DEEP) return rt_upload_scene(scene);                       // the host builder bounds the depth
+    if (st != rtg::BUILD_OK) return fail(err);
+    if (!rtp::validate_header(built.header, built.bytes, &err)) { (void)hipFree(built.d_blob); return fail(err); }
+    release_scene();
+    g.d_blob = built.d_blob; g.blob_bytes = built.bytes; g.blob_owned = true;
+    g.info = rt_bvh_info{};
+    point_at_blob(g.d_blob, built.header);
+    g.info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }
 

@@ -123,6 +123,114 @@ bool validate_blob(const uint8_t* blob, size_t bytes, std::string* err) {
     return true;
 }
 
+bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
+    if ((s.ntri && (!s.tri_v0 || !s.tri_v1 || !s.tri_v2 || !s.tri_mat)) || (s.nsph && (!s.sph_center || !s.sph_radius || !s.sph_mat)) ||
+        (s.npl && (!s.pl_point || !s.pl_normal || !s.pl_mat)) || (s.nlights && !s.lights)) {
+        *err = "rt_scene: a non-empty array is NULL";
+        return false;
+    }
+    const uint64_t total = (uint64_t)s.ntri + s.nsph + s.npl;
+    if (total > rtl::MAX_TREE_SHAPES) { *err = "rt_scene: too many shapes"; return false; }
+    const uint32_t bounded = s.ntri + s.nsph;
+    out->use_tree = bounded > SMALL_SCENE;
+    if (!out->use_tree) return true;
+
+    // Material ids in file-independent but deterministic order (triangles, spheres, planes).  Shapes copy
+    // the parser's current material (config_builder.rs:401-403): runs of equal materials are the rule,
+    // so the table is only consulted where a run ends.
+    std::unordered_map<MatKey, uint32_t, MatHash> mat_ids;
+    std::vector<uint32_t> tri_ids(s.ntri), sph_ids(s.nsph), pl_ids(s.npl);
+    auto assign_ids = [&](const float* mats, uint32_t n, uint32_t* ids) {
+        const float* prev = nullptr; uint32_t prev_id = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const float* m = mats + 7 * (size_t)i;
+            if (!prev || std::memcmp(m, prev, 28) != 0) {
+                MatKey k; std::memcpy(k.w, m, sizeof(k.w));
+                auto it = mat_ids.find(k);
+                if (it == mat_ids.end()) {
+                    rtl::MaterialRec r{};
+                    r.diffuse[0] = m[0]; r.diffuse[1] = m[1]; r.diffuse[2] = m[2]; r.specular[0] = m[3]; r.specular[1] = m[4]; r.specular[2] = m[5];
+                    r.shininess = m[6];
+                    it = mat_ids.emplace(k, (uint32_t)out->mats.size()).first;
+                    out->mats.push_back(r);
+                }
+                prev = m; prev_id = it->second;
+            }
+            ids[i] = prev_id;
+        }
+    };
+    assign_ids(s.tri_mat, s.ntri, tri_ids.data());
+    assign_ids(s.sph_mat, s.nsph, sph_ids.data());
+    assign_ids(s.pl_mat, s.npl, pl_ids.data());
+    if (out->mats.size() >= (1u << 30)) { *err = "rt_scene: too many distinct materials"; return false; }
+
+    auto flat_of = [&](uint32_t j) {       // bounded shape j: triangles first, then spheres
+        if (j < s.ntri) return Flat{rtl::KIND_TRIANGLE, j, s.tri_order ? s.tri_order[j] : j, tri_ids[j]};
+        const uint32_t i = j - s.ntri;
+        return Flat{rtl::KIND_SPHERE, i, s.sph_order ? s.sph_order[i] : s.ntri + i, sph_ids[i]};
+    };
+    out->tree.resize(bounded);
+#pragma omp parallel for schedule(static) if (bounded > 100000)
+    for (int64_t j = 0; j < (int64_t)bounded; j++) fill_record(s, flat_of((uint32_t)j), &out->tree[(size_t)j]);
+    for (uint32_t i = 0; i < s.npl; i++) {
+        rtl::ShapeRec r; fill_record(s, Flat{rtl::KIND_PLANE, i, s.pl_order ? s.pl_order[i] : s.ntri + s.nsph + i, pl_ids[i]}, &r);
+        out->list.push_back(r);
+    }
+
+    // Extent of the bulk of the scene from a sample of the box centres (5th..95th percentile), for the
+    // absolute padding and for spotting the few shapes far larger than everything else.
+    auto box_of = [](const rtl::ShapeRec& r, int k, float* lo, float* hi) {
+        if ((r.kind_mat & 3u) == rtl::KIND_SPHERE) { *lo = r.q0[k] - r.q1[0]; *hi = r.q0[k] + r.q1[0]; }
+        else { *lo = std::min(std::min(r.q0[k], r.q1[k]), r.q2[k]); *hi = std::max(std::max(r.q0[k], r.q1[k]), r.q2[k]); }
+    };
+    const size_t stride = std::max<size_t>(1, bounded / 65536);
+    float extent = 0.0f;
+    for (int k = 0; k < 3; k++) {
+        std::vector<float> c;
+        for (size_t j = 0; j < bounded; j += stride) { float lo, hi; box_of(out->tree[j], k, &lo, &hi); c.push_back(0.5f * lo + 0.5f * hi); }
+        const size_t a = c.size() / 20, b = c.size() - 1 - c.size() / 20;
+        std::nth_element(c.begin(), c.begin() + (ptrdiff_t)a, c.end()); const float p5 = c[a];
+        std::nth_element(c.begin(), c.begin() + (ptrdiff_t)b, c.end()); const float p95 = c[b];
+        if (std::isfinite(p95 - p5)) extent = std::max(extent, p95 - p5);
+    }
+    out->pad_abs = extent * 4e-6f;
+    if (extent > 0.0f) {
+        std::vector<uint32_t> big;
+#pragma omp parallel for schedule(static) if (bounded > 100000)
+        for (int64_t j = 0; j < (int64_t)bounded; j++) {
+            bool oversize = false;
+            for (int k = 0; k < 3; k++) { float lo, hi; box_of(out->tree[(size_t)j], k, &lo, &hi); oversize = oversize || hi - lo > 32.0f * extent; }
+            if (oversize) {
+#pragma omp critical
+                big.push_back((uint32_t)j);
+            }
+        }
+        if (!big.empty() && big.size() <= SMALL_SCENE && bounded - big.size() > SMALL_SCENE) {
+            std::sort(big.begin(), big.end());
+            for (size_t b = big.size(); b-- > 0;) {          // the order of the tree records is free: fill the hole with the last one
+                out->list.push_back(out->tree[big[b]]);
+                out->tree[big[b]] = out->tree.back();
+                out->tree.pop_back();
+            }
+        }
+    }
+    std::sort(out->list.begin(), out->list.end(), [](const rtl::ShapeRec& a, const rtl::ShapeRec& b) { return a.order < b.order; });
+
+    out->lights.resize(s.nlights);
+    bool finite = true;
+    for (const rtl::MaterialRec& m : out->mats)
+        for (int k = 0; k < 3; k++) finite = finite && std::isfinite(m.diffuse[k]) && std::isfinite(m.specular[k]);
+    for (uint32_t i = 0; i < s.nlights; i++) {
+        const float* l = s.lights + 7 * (size_t)i;
+        if (!(l[0] == 0.0f || l[0] == 1.0f)) { *err = "rt_scene: light kind must be 0 (point) or 1 (directional)"; return false; }
+        rtl::LightRec& r = out->lights[i];
+        r.kind = l[0]; r.v[0] = l[1]; r.v[1] = l[2]; r.v[2] = l[3]; r.color[0] = l[4]; r.color[1] = l[5]; r.color[2] = l[6]; r.pad = 0.0f;
+        for (int k = 1; k < 7; k++) finite = finite && std::isfinite(l[k]);
+    }
+    out->finite_shading = finite ? 1u : 0u;
+    return true;
+}
+
 bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info, std::string* err) {
     auto t0 = std::chrono::steady_clock::now();
     if ((s.ntri && (!s.tri_v0 || !s.tri_v1 || !s.tri_v2 || !s.tri_mat)) || (s.nsph && (!s.sph_center || !s.sph_radius || !s.sph_mat)) ||

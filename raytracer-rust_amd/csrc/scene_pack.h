@@ -21,6 +21,20 @@ constexpr uint32_t TREE_DEPTH_LIMIT = 63;
 
 bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info, std::string* err);
 
+// The same scene split into the parts of a blob without a tree, for the GPU tree builder: shape
+// records of the tree shapes in input order (triangles, then spheres), the always-tested list in
+// file order, the material table, the lights, and the padding rule of the node boxes.
+// use_tree is false for scenes so small that every shape goes to the list (then pack_scene is the way).
+struct SceneParts {
+    std::vector<rtl::ShapeRec> tree, list;
+    std::vector<rtl::MaterialRec> mats;
+    std::vector<rtl::LightRec> lights;
+    uint32_t finite_shading = 1;
+    float pad_abs = 0.0f;
+    bool use_tree = false;
+};
+bool split_scene(const rt_scene& s, SceneParts* out, std::string* err);
+
 // Checks a blob header copied back from the device before the kernels are pointed at it.
 bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err);
 

@@ -128,7 +128,7 @@ class ShardedRenderer:
             self._complete()
 
 
-def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gather=False):
+def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gather=False, gpu_build=False):
     """ShardedRenderer on one MI355X: uploads (rank 0) or receives (other ranks) the scene and wires the
     library's tile rendering and frame assembly in.  Returns (renderer, bvh_info or None)."""
     import torch
@@ -142,7 +142,7 @@ def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gathe
     info, keep = None, None
     if rank == 0:
         assert scene is not None, "rank 0 must be given the scene"
-        info = rt.upload_scene(scene)                                  # RayTracer::new on the owning rank
+        info = rt.upload_scene(scene, gpu_build=gpu_build)             # RayTracer::new on the owning rank
     if world > 1 or (always_gather and dist.is_initialized()):
         buf = None
         if rank == 0:
