@@ -107,7 +107,7 @@ struct Builder {
         n_leaves.fetch_add(1, std::memory_order_relaxed);
         atomic_max(max_depth, depth);
         atomic_max(max_leaf, count);
-        // Shapes inside a leaf in file order: the scan inside a leaf then breaks ties like a file-order scan.
+        // Shapes inside a leaf in input order, so that the result does not depend on how the threads interleaved.
         std::sort(idx.begin() + first, idx.begin() + first + count, [&](uint32_t a, uint32_t b) { return perm[a] < perm[b]; });
         return rtl::make_leaf_ref(first, count);
     }

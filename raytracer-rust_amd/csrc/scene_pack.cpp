@@ -133,7 +133,6 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
     if (total > rtl::MAX_TREE_SHAPES) { *err = "rt_scene: too many shapes"; return false; }
     const uint32_t bounded = s.ntri + s.nsph;
     out->use_tree = bounded > SMALL_SCENE;
-    if (!out->use_tree) return true;
 
     // Material ids in file-independent but deterministic order (triangles, spheres, planes).  Shapes copy
     // the parser's current material (config_builder.rs:401-403): runs of equal materials are the rule,
@@ -172,6 +171,7 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
     out->tree.resize(bounded);
 #pragma omp parallel for schedule(static) if (bounded > 100000)
     for (int64_t j = 0; j < (int64_t)bounded; j++) fill_record(s, flat_of((uint32_t)j), &out->tree[(size_t)j]);
+    if (!out->use_tree) { out->list.swap(out->tree); }      // a handful of shapes: all of them are tested for every ray
     for (uint32_t i = 0; i < s.npl; i++) {
         rtl::ShapeRec r; fill_record(s, Flat{rtl::KIND_PLANE, i, s.pl_order ? s.pl_order[i] : s.ntri + s.nsph + i, pl_ids[i]}, &r);
         out->list.push_back(r);
@@ -183,11 +183,12 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
         if ((r.kind_mat & 3u) == rtl::KIND_SPHERE) { *lo = r.q0[k] - r.q1[0]; *hi = r.q0[k] + r.q1[0]; }
         else { *lo = std::min(std::min(r.q0[k], r.q1[k]), r.q2[k]); *hi = std::max(std::max(r.q0[k], r.q1[k]), r.q2[k]); }
     };
-    const size_t stride = std::max<size_t>(1, bounded / 65536);
+    const size_t ntree = out->tree.size();
+    const size_t stride = std::max<size_t>(1, ntree / 65536);
     float extent = 0.0f;
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 3 && ntree > 0; k++) {
         std::vector<float> c;
-        for (size_t j = 0; j < bounded; j += stride) { float lo, hi; box_of(out->tree[j], k, &lo, &hi); c.push_back(0.5f * lo + 0.5f * hi); }
+        for (size_t j = 0; j < ntree; j += stride) { float lo, hi; box_of(out->tree[j], k, &lo, &hi); c.push_back(0.5f * lo + 0.5f * hi); }
         const size_t a = c.size() / 20, b = c.size() - 1 - c.size() / 20;
         std::nth_element(c.begin(), c.begin() + (ptrdiff_t)a, c.end()); const float p5 = c[a];
         std::nth_element(c.begin(), c.begin() + (ptrdiff_t)b, c.end()); const float p95 = c[b];
@@ -196,8 +197,8 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
     out->pad_abs = extent * 4e-6f;
     if (extent > 0.0f) {
         std::vector<uint32_t> big;
-#pragma omp parallel for schedule(static) if (bounded > 100000)
-        for (int64_t j = 0; j < (int64_t)bounded; j++) {
+#pragma omp parallel for schedule(static) if (ntree > 100000)
+        for (int64_t j = 0; j < (int64_t)ntree; j++) {
             bool oversize = false;
             for (int k = 0; k < 3; k++) { float lo, hi; box_of(out->tree[(size_t)j], k, &lo, &hi); oversize = oversize || hi - lo > 32.0f * extent; }
             if (oversize) {
@@ -205,7 +206,7 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
                 big.push_back((uint32_t)j);
             }
         }
-        if (!big.empty() && big.size() <= SMALL_SCENE && bounded - big.size() > SMALL_SCENE) {
+        if (!big.empty() && big.size() <= SMALL_SCENE && ntree - big.size() > SMALL_SCENE) {
             std::sort(big.begin(), big.end());
             for (size_t b = big.size(); b-- > 0;) {          // the order of the tree records is free: fill the hole with the last one
                 out->list.push_back(out->tree[big[b]]);
@@ -233,110 +234,32 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
 
 bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info, std::string* err) {
     auto t0 = std::chrono::steady_clock::now();
-    if ((s.ntri && (!s.tri_v0 || !s.tri_v1 || !s.tri_v2 || !s.tri_mat)) || (s.nsph && (!s.sph_center || !s.sph_radius || !s.sph_mat)) ||
-        (s.npl && (!s.pl_point || !s.pl_normal || !s.pl_mat)) || (s.nlights && !s.lights)) {
-        *err = "rt_scene: a non-empty array is NULL";
-        return false;
-    }
-    uint64_t total = (uint64_t)s.ntri + s.nsph + s.npl;
-    if (total > rtl::MAX_TREE_SHAPES) { *err = "rt_scene: too many shapes"; return false; }
-
-    // File order of every shape (ties on exactly equal distance go to the earlier shape).
-    std::vector<Flat> flat; flat.reserve(total);
-    for (uint32_t i = 0; i < s.ntri; i++) flat.push_back({rtl::KIND_TRIANGLE, i, s.tri_order ? s.tri_order[i] : i, 0});
-    for (uint32_t i = 0; i < s.nsph; i++) flat.push_back({rtl::KIND_SPHERE, i, s.sph_order ? s.sph_order[i] : s.ntri + i, 0});
-    for (uint32_t i = 0; i < s.npl; i++) flat.push_back({rtl::KIND_PLANE, i, s.pl_order ? s.pl_order[i] : s.ntri + s.nsph + i, 0});
-
-    // Material table: shapes copy the parser's current material (config_builder.rs:401-403), so
-    // a scene has few distinct ones.
-    std::unordered_map<MatKey, uint32_t, MatHash> mat_ids;
-    std::vector<rtl::MaterialRec> mats;
-    for (Flat& f : flat) {
-        const float* m = f.kind == rtl::KIND_TRIANGLE ? s.tri_mat + 7 * (size_t)f.idx_in_kind
-                       : f.kind == rtl::KIND_SPHERE ? s.sph_mat + 7 * (size_t)f.idx_in_kind : s.pl_mat + 7 * (size_t)f.idx_in_kind;
-        MatKey k; std::memcpy(k.w, m, sizeof(k.w));
-        auto it = mat_ids.find(k);
-        if (it == mat_ids.end()) {
-            rtl::MaterialRec r{};
-            r.diffuse[0] = m[0]; r.diffuse[1] = m[1]; r.diffuse[2] = m[2]; r.specular[0] = m[3]; r.specular[1] = m[4]; r.specular[2] = m[5];
-            r.shininess = m[6];
-            it = mat_ids.emplace(k, (uint32_t)mats.size()).first;
-            mats.push_back(r);
-            if (mats.size() >= (1u << 30)) { *err = "rt_scene: too many distinct materials"; return false; }
-        }
-        f.mat = it->second;
-    }
-
-    // Split into always-tested shapes and tree shapes.
-    uint32_t bounded = s.ntri + s.nsph;
-    bool use_tree = bounded > SMALL_SCENE;
-    std::vector<Flat> list_shapes, tree_in;
-    for (const Flat& f : flat) {
-        if (f.kind == rtl::KIND_PLANE || !use_tree) list_shapes.push_back(f); else tree_in.push_back(f);
-    }
-    std::sort(list_shapes.begin(), list_shapes.end(), [](const Flat& a, const Flat& b) { return a.order < b.order; });
+    SceneParts parts;
+    if (!split_scene(s, &parts, err)) return false;
+    const std::vector<rtl::ShapeRec>& list_shapes = parts.list;
+    const std::vector<rtl::MaterialRec>& mats = parts.mats;
 
     // Boxes of the tree shapes (shape.rs:208-234).
-    size_t nt = tree_in.size();
+    const size_t nt = parts.tree.size();
     std::vector<float> lo(3 * nt), hi(3 * nt);
     bool finite_boxes = true;
 #pragma omp parallel for schedule(static) reduction(&& : finite_boxes) if (nt > 100000)
     for (int64_t jj = 0; jj < (int64_t)nt; jj++) {
         const size_t j = (size_t)jj;
-        const Flat& f = tree_in[j]; size_t i = f.idx_in_kind;
+        const rtl::ShapeRec& r = parts.tree[j];
         for (int k = 0; k < 3; k++) {
-            if (f.kind == rtl::KIND_SPHERE) {
-                lo[3 * j + k] = s.sph_center[3 * i + k] - s.sph_radius[i];
-                hi[3 * j + k] = s.sph_center[3 * i + k] + s.sph_radius[i];
-            } else {
-                float a = s.tri_v0[3 * i + k], b = s.tri_v1[3 * i + k], c = s.tri_v2[3 * i + k];
-                lo[3 * j + k] = std::min(std::min(a, b), c);
-                hi[3 * j + k] = std::max(std::max(a, b), c);
+            if ((r.kind_mat & 3u) == rtl::KIND_SPHERE) { lo[3 * j + k] = r.q0[k] - r.q1[0]; hi[3 * j + k] = r.q0[k] + r.q1[0]; }
+            else {
+                lo[3 * j + k] = std::min(std::min(r.q0[k], r.q1[k]), r.q2[k]);
+                hi[3 * j + k] = std::max(std::max(r.q0[k], r.q1[k]), r.q2[k]);
             }
             if (!std::isfinite(lo[3 * j + k]) || !std::isfinite(hi[3 * j + k])) finite_boxes = false;
         }
     }
     if (!finite_boxes) { *err = "rt_scene: non-finite shape coordinates"; return false; }
-    // Absolute padding: a few parts per million of the extent that holds the bulk of the shapes
-    // (5th..95th percentile of the box centres, so one huge ground sphere does not set the scale).
-    float pad_abs = 0.0f;
-    if (nt > 0) {
-        float extent = 0.0f;
-        std::vector<float> c(nt);
-        for (int k = 0; k < 3; k++) {
-            for (size_t j = 0; j < nt; j++) c[j] = 0.5f * lo[3 * j + k] + 0.5f * hi[3 * j + k];
-            size_t a = nt / 20, b = nt - 1 - nt / 20;
-            std::nth_element(c.begin(), c.begin() + a, c.end()); float p5 = c[a];
-            std::nth_element(c.begin(), c.begin() + b, c.end()); float p95 = c[b];
-            extent = std::max(extent, p95 - p5);
-        }
-        pad_abs = extent * 4e-6f;
-    }
-
-    // Shapes far larger than the bulk of the scene (a ground sphere of radius 10000 under unit
-    // spheres) would stretch the 16-bit node grid for everybody: when there are only a few, they
-    // join the always-tested list instead of the tree.
-    if (nt > 0 && pad_abs > 0.0f) {
-        const float extent = pad_abs / 4e-6f;
-        std::vector<size_t> big;
-        for (size_t j = 0; j < nt && big.size() <= SMALL_SCENE; j++)
-            for (int k = 0; k < 3; k++)
-                if (hi[3 * j + k] - lo[3 * j + k] > 32.0f * extent) { big.push_back(j); break; }
-        if (!big.empty() && big.size() <= SMALL_SCENE && nt - big.size() > SMALL_SCENE) {
-            for (size_t b = big.size(); b-- > 0;) {
-                size_t j = big[b];
-                list_shapes.push_back(tree_in[j]);
-                tree_in.erase(tree_in.begin() + (ptrdiff_t)j);
-                lo.erase(lo.begin() + 3 * (ptrdiff_t)j, lo.begin() + 3 * (ptrdiff_t)j + 3);
-                hi.erase(hi.begin() + 3 * (ptrdiff_t)j, hi.begin() + 3 * (ptrdiff_t)j + 3);
-            }
-            nt = tree_in.size();
-            std::sort(list_shapes.begin(), list_shapes.end(), [](const Flat& a, const Flat& b) { return a.order < b.order; });
-        }
-    }
 
     rtb::BvhResult bvh;
-    if (!rtb::build_bvh(lo.data(), hi.data(), (uint32_t)nt, TREE_DEPTH_LIMIT, pad_abs, &bvh, err)) return false;
+    if (!rtb::build_bvh(lo.data(), hi.data(), (uint32_t)nt, TREE_DEPTH_LIMIT, parts.pad_abs, &bvh, err)) return false;
 
     // Assemble the blob.
     rtl::BlobHeader h{};
@@ -351,12 +274,7 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
     h.off_materials = off; off = align256(off + mats.size() * sizeof(rtl::MaterialRec));
     h.off_lights = off; off = align256(off + (size_t)s.nlights * sizeof(rtl::LightRec));
     h.total_bytes = off;
-    bool finite = true;
-    for (const rtl::MaterialRec& m : mats)
-        for (int k = 0; k < 3; k++) finite = finite && std::isfinite(m.diffuse[k]) && std::isfinite(m.specular[k]);
-    for (uint32_t i = 0; i < s.nlights; i++)
-        for (int k = 1; k < 7; k++) finite = finite && std::isfinite(s.lights[7 * (size_t)i + k]);
-    h.finite_shading = finite ? 1u : 0u;
+    h.finite_shading = parts.finite_shading;
     blob->assign(off, 0);
     // Quantise the (already padded) builder boxes outwards onto the 16-bit scene grid.
     {
@@ -397,17 +315,10 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
     std::memcpy(blob->data(), &h, sizeof(h));        // after the grid has been filled in
     rtl::ShapeRec* ts = (rtl::ShapeRec*)(blob->data() + h.off_tree_shapes);
 #pragma omp parallel for schedule(static) if (nt > 100000)
-    for (int64_t j = 0; j < (int64_t)nt; j++) fill_record(s, tree_in[bvh.order[j]], &ts[j]);
-    rtl::ShapeRec* ls = (rtl::ShapeRec*)(blob->data() + h.off_list_shapes);
-    for (size_t j = 0; j < list_shapes.size(); j++) fill_record(s, list_shapes[j], &ls[j]);
+    for (int64_t j = 0; j < (int64_t)nt; j++) ts[j] = parts.tree[bvh.order[(size_t)j]];
+    if (!list_shapes.empty()) std::memcpy(blob->data() + h.off_list_shapes, list_shapes.data(), list_shapes.size() * sizeof(rtl::ShapeRec));
     if (!mats.empty()) std::memcpy(blob->data() + h.off_materials, mats.data(), mats.size() * sizeof(rtl::MaterialRec));
-    rtl::LightRec* lr = (rtl::LightRec*)(blob->data() + h.off_lights);
-    for (uint32_t i = 0; i < s.nlights; i++) {
-        const float* l = s.lights + 7 * (size_t)i;
-        if (!(l[0] == 0.0f || l[0] == 1.0f)) { *err = "rt_scene: light kind must be 0 (point) or 1 (directional)"; return false; }
-        lr[i].kind = l[0]; lr[i].v[0] = l[1]; lr[i].v[1] = l[2]; lr[i].v[2] = l[3];
-        lr[i].color[0] = l[4]; lr[i].color[1] = l[5]; lr[i].color[2] = l[6]; lr[i].pad = 0.0f;
-    }
+    if (!parts.lights.empty()) std::memcpy(blob->data() + h.off_lights, parts.lights.data(), parts.lights.size() * sizeof(rtl::LightRec));
     if (info) {
         info->node_pairs = h.n_pairs; info->leaves = h.n_leaves; info->max_depth = h.max_depth; info->max_leaf = h.max_leaf;
         info->bvh_prims = h.n_tree_shapes; info->list_prims = h.n_list_shapes; info->sah_cost = bvh.sah_cost;

@@ -60,6 +60,8 @@ pub struct rt_stats {
     pub total_ms: f64,
 }
 
+pub const RT_BUILD_ON_GPU: u32 = 1;
+
 /// Opaque handles of `include/rt_host.h`.
 #[repr(C)]
 pub struct rth_config { _private: [u8; 0] }
@@ -69,6 +71,8 @@ pub struct rth_scene_cache { _private: [u8; 0] }
 extern "C" {
     pub fn rt_init(device: c_int) -> c_int;
     pub fn rt_upload_scene(scene: *const rt_scene) -> c_int;
+    /// `flags`: `RT_BUILD_ON_GPU` builds the tree on the GPU (faster start, somewhat slower frames).
+    pub fn rt_upload_scene_ex(scene: *const rt_scene, flags: u32) -> c_int;
     pub fn rt_upload_scene_blob(host_blob: *const c_void, bytes: usize) -> c_int;
     pub fn rt_download_scene_blob(host_dst: *mut c_void, bytes: usize) -> c_int;
     pub fn rt_compare_frames(d_a: *const u32, width_a: u32, height_a: u32, d_b: *const u32, width_b: u32, height_b: u32,

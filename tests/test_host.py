@@ -343,14 +343,11 @@ def _check_tree(b):
             first, cnt = (ref & 0x7FFFFFFF) >> 3, (ref & 7) + 1
             leaves += 1
             max_depth = max(max_depth, depth)
-            orders = []
             for k in range(first, first + cnt):
                 seen[k] += 1
                 slo, shi = shape_box(tree[k], tf[k])
                 if lo is not None:
                     assert (slo >= lo).all() and (shi <= hi).all(), "leaf box does not contain its shape"
-                orders.append(int(tree[k][7]))
-            assert orders == sorted(orders)
             continue
         for c in (0, 1):
             clo, chi = child_box(ref, c)
