@@ -315,7 +315,7 @@ struct DeviceBuffers {               // everything the build needs besides the b
 
 BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltScene* out, std::string* err) {
     const uint32_t n = in.n_tree;
-    if (n < 2 || n > rtl::MAX_TREE_SHAPES) { *err = "GPU tree build needs between 2 and 2^28 - 2 shapes"; return BUILD_FAILED; }
+    if (n < 2 || n > rtl::MAX_TREE_SHAPES) { *err = "GPU tree build needs between 2 and 2^27 shapes"; return BUILD_FAILED; }
     const uint32_t blocks_n = (n + 255) / 256, blocks_i = (n - 1 + 255) / 256;
     DeviceBuffers mem;
     rtl::ShapeRec* d_rec; float4 *d_lo, *d_hi, *d_slo, *d_shi; Bounds* d_bounds;

@@ -36,7 +36,7 @@ constexpr uint32_t KIND_SPHERE = 0, KIND_TRIANGLE = 1, KIND_PLANE = 2;
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_EMPTY = 0xFFFFFFFFu;   // never produced for a real leaf (would need first = 2^28 - 1)
 constexpr uint32_t MAX_LEAF = 8;
-constexpr uint32_t MAX_TREE_SHAPES = (1u << 28) - 2;
+constexpr uint32_t MAX_TREE_SHAPES = 1u << 27;   // fewer node pairs than 2^27: the kernels address the node array with 32-bit byte offsets
 
 inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return REF_LEAF | (first << 3) | (count - 1); }
 

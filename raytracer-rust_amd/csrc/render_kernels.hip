@@ -170,7 +170,11 @@ __device__ __forceinline__ bool slab(const uint4 c, const RayBox& rb, float tlim
     const float ay = fmaf(ly, rb.A.y, rb.Blo.y), by = fmaf(hy, rb.A.y, rb.Bhi.y);
     const float az = fmaf(lz, rb.A.z, rb.Blo.z), bz = fmaf(hz, rb.A.z, rb.Bhi.z);
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tlim));
+    // The limit goes in through a bare v_min_f32: the compiler would otherwise re-canonicalise it in every pass
+    // (it cannot see through the loop that the value is never a signalling NaN).
+    float zlim;
+    asm("v_min_f32 %0, %1, %2" : "=v"(zlim) : "v"(fmaxf(az, bz)), "v"(tlim));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), zlim);
     *tnear = tn;
     return tn <= tf;
 }
@@ -201,14 +205,14 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
     if (cur == REF_EMPTY) return;
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = best->prim == NO_PRIM ? INF : prune_limit(best->t);
-    uint32_t sp = 1;                                    // entry 0 of every lane's stack holds REF_EMPTY: popping needs no emptiness test
+    uint32_t* top = stack + 64;                         // next free entry; entry 0 of every lane's stack holds REF_EMPTY: popping needs no emptiness test
     // All lanes descend through inner nodes until each has reached a leaf (or run out of nodes),
     // then all test their leaves together.  A lane that reaches its leaf early sets it aside and
     // keeps descending towards its next one instead of idling (it then tests both).
     uint32_t held = 0;                                  // leaf set aside (leaf references are never 0)
     for (;;) {
         while (!(cur & REF_LEAF)) {
-            const uint4* n = sc.nodes + 2 * (size_t)cur;
+            const uint4* n = (const uint4*)((const char*)sc.nodes + (cur << 5));   // 32-byte pairs; a 32-bit offset keeps the address in one register
             const uint4 c0 = n[0], c1 = n[1];
             float t0, t1;
             bool h0 = slab(c0, rb, tlim, &t0);
@@ -217,20 +221,20 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             uint32_t r0 = c0.w, r1 = c1.w;
             if (h0 && h1) {
                 bool swap = t1 < t0;
-                stack[sp * 64] = swap ? r0 : r1; sp++;
+                *top = swap ? r0 : r1; top += 64;
                 cur = swap ? r1 : r0;
             } else if (h0) cur = r0;
             else if (h1) cur = r1;
-            else { sp--; cur = stack[sp * 64]; }
+            else { top -= 64; cur = *top; }
             if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {
                 held = cur;
-                sp--; cur = stack[sp * 64];
+                top -= 64; cur = *top;
             }
-            if (!__any(held == 0 && !(cur & REF_LEAF))) break;    // nobody is still looking for a first leaf
+            if (__builtin_amdgcn_ballot_w64(held == 0 && !(cur & REF_LEAF)) == 0) break;    // nobody is still looking for a first leaf
         }
         if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf
             held = cur;
-            sp--; cur = stack[sp * 64];
+            top -= 64; cur = *top;
         }
         while (held != 0) {
             uint32_t first = (held & ~REF_LEAF) >> 3, count = (held & 7u) + 1u;
@@ -247,7 +251,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             held = 0;
             if ((cur & REF_LEAF) && cur != REF_EMPTY) {
                 held = cur;
-                sp--; cur = stack[sp * 64];
+                top -= 64; cur = *top;
             }
         }
         if (cur == REF_EMPTY) break;
@@ -276,20 +280,20 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
     if (cur == REF_EMPTY) return false;
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = point_light ? prune_limit(light_dist) : INF;
-    uint32_t sp = 1;
+    uint32_t* top = stack + 64;
     while (cur != REF_EMPTY) {
         while (!(cur & REF_LEAF)) {
-            const uint4* n = sc.nodes + 2 * (size_t)cur;
+            const uint4* n = (const uint4*)((const char*)sc.nodes + (cur << 5));   // 32-byte pairs; a 32-bit offset keeps the address in one register
             const uint4 c0 = n[0], c1 = n[1];
             float t0, t1;
             bool h0 = slab(c0, rb, tlim, &t0);
             bool h1 = slab(c1, rb, tlim, &t1);
             if (COUNT) { cnt->nodes += 2; if (first_active_lane()) cnt->wave_node_iters++; }
             uint32_t r0 = c0.w, r1 = c1.w;
-            if (h0 && h1) { stack[sp * 64] = r1; sp++; cur = r0; }
+            if (h0 && h1) { *top = r1; top += 64; cur = r0; }
             else if (h0) cur = r0;
             else if (h1) cur = r1;
-            else { sp--; cur = stack[sp * 64]; }
+            else { top -= 64; cur = *top; }
         }
         if (cur != REF_EMPTY) {
             uint32_t first = (cur & ~REF_LEAF) >> 3, count = (cur & 7u) + 1u;
@@ -298,7 +302,7 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
                 if (COUNT) { cnt->prims++; if (first_active_lane()) cnt->wave_prim_iters++; }
                 if (occludes(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
             }
-            sp--; cur = stack[sp * 64];
+            top -= 64; cur = *top;
         }
     }
     return false;

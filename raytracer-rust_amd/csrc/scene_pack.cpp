@@ -62,6 +62,7 @@ bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err) {
         *err = "scene blob: section outside the buffer";
         return false;
     }
+    if (h.n_pairs >= (1u << 27)) { *err = "scene blob: too many node pairs for 32-bit offsets"; return false; }
     if (h.max_depth > TREE_DEPTH_LIMIT) { *err = "scene blob: tree deeper than the traversal stack"; return false; }
     if (h.root_ref != rtl::REF_EMPTY) {
         if (h.root_ref & rtl::REF_LEAF) {
