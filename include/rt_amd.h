@@ -81,7 +81,7 @@ typedef struct rt_stats {
     uint64_t primary;        /* primary rays   = pixels rendered by this call               */
     uint64_t shadow;         /* shadow rays    = one per (hit, light)     raytracer.rs:126-141 */
     uint64_t secondary;      /* reflection rays actually spawned          raytracer.rs:192  */
-    uint64_t nodes_visited;  /* bounding boxes tested (32 bytes each)                       */
+    uint64_t nodes_visited;  /* bounding boxes tested (two per node pair visited)           */
     uint64_t prims_tested;   /* exact shape tests (48 bytes each)                           */
     uint64_t box_passes;     /* instrumented runs: wavefront-level passes of the box-test loop; lane use =
                                 nodes_visited / 2 / (64 * box_passes)                                   */
@@ -92,13 +92,13 @@ typedef struct rt_stats {
 
 /* rt_build information about the tree the library built for the resident scene. */
 typedef struct rt_bvh_info {
-    uint32_t node_pairs;     /* 64-byte records: two 32-byte child boxes each               */
+    uint32_t node_pairs;     /* 32-byte records: two 16-byte child boxes (16-bit grid) each */
     uint32_t leaves;
-    uint32_t max_depth;
+    uint32_t max_depth;      /* node pairs on the longest root-to-leaf path (at most 63)    */
     uint32_t max_leaf;       /* largest number of shapes in one leaf                        */
     uint32_t bvh_prims;      /* shapes inside the tree                                      */
     uint32_t list_prims;     /* shapes always tested (planes; everything in tiny scenes)    */
-    double build_ms;
+    double build_ms;         /* host time of the upload call that made the scene resident; 0 for adopted or cached blobs */
     double sah_cost;
 } rt_bvh_info;
 

@@ -437,6 +437,25 @@ def test_gpu_built_tree_of_the_large_mesh_matches_the_host_built_one():
     print("1M-triangle mesh, GPU tree:", info)
 
 
+@pytest.mark.parametrize("text", [
+    "size 33 17\n",                                                                    # nothing at all: every ray misses
+    "size 33 17\npoint 0 5 5 1 1 1\n",                                                 # lights but no shapes
+    "size 33 17\nmaxdepth 0\ndiffuse .5 .5 .5\nspecular .5 .5 .5\nplane 0 -1 0 0 1 0\npoint 0 5 5 1 1 1\n",   # a plane only, maxdepth 0
+    "size 33 17\nmaxdepth 7\ndiffuse .2 .2 .2\nspecular .9 .9 .9\nshininess 1\nplane 0 -1 0 0 1 0\nplane 0 3 0 0 -1 0\nsphere 0 0 4 1\n"
+    "directional 0 1 1 .6 .6 .6\npoint 0 0 0 .4 .4 .4\n",                               # facing mirrors, shininess 1, both light kinds
+], ids=["empty", "lights-only", "plane-maxdepth0", "mirrors"])
+def test_tiny_and_empty_scenes(text):
+    cfg = rt.ParsedConfigState().parse_text(text)
+    for gpu_build in (False, True):
+        tracer = rt.RayTracer(cfg, gpu_build=gpu_build)
+        img = tracer.render(count_work=True)
+        want, st = O.OracleScene.parse(text).render(mode=O.OracleScene.MODE_ALL)
+        c = _assert_parity(img.pixels(), want)
+        assert c["identical_frac"] == 1.0, c
+        got = tracer.last_stats
+        assert (got["primary"], got["shadow"], got["secondary"]) == (st["primary"], st["shadow"], st["secondary"])
+
+
 def test_errors_are_reported_not_fatal():
     cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "test_file", "jalon3", "tp31.test"))
     rt.RayTracer.new(cfg)
