@@ -28,7 +28,28 @@ struct DevFrame {
     // Otherwise the frame is cut into square regions of (1 << region_log2)^2 tiles and the blocks
     // that share an XCD (b, b + 8, b + 16, ...) walk through one region after another.
     uint32_t region_log2, regions_x, n_regions;
+    // Order in which the regions are handed out (n_regions entries, device memory; nullptr = region i at position i)
+    // and, per region, the run time of its slowest wavefront in this launch (10 ns units; nullptr = not recorded),
+    // from which the order of the next launch of the same frame geometry is made.
+    const uint32_t* region_order;
+    uint32_t* region_cost;
 };
+
+
+constexpr uint32_t MAX_SORTED_REGIONS = 4096;   // what one workgroup sorts in LDS
+
+// Region size for a launch of tiles_x x tiles_y pixel tiles: 0 = row-major tile order.
+// Frames of fewer than 2048 tiles keep row-major order; otherwise the smallest regions (from 8x8 tiles up) that
+// number at most MAX_SORTED_REGIONS, so that the order can follow measured costs as finely as possible.
+inline uint32_t region_log2_for(uint64_t tiles) {
+    if (tiles < (1u << 11)) return 0u;
+    uint32_t l = 3;
+    while ((tiles >> (2 * l)) > 3072u && l < 12u) l++;     // leaves room for the partial regions at the frame's edges
+    return l;
+}
+
+// regions[order[i]] by decreasing cost into `order` (n <= MAX_SORTED_REGIONS), ties by index.
+extern "C" hipError_t rtk_launch_sort_regions(const uint32_t* d_cost, uint32_t n, uint32_t* d_order, hipStream_t stream);
 
 extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, uint32_t* d_out, float4* d_fold,
                                         unsigned long long* d_counters, int stack_depth, int count, hipStream_t stream);

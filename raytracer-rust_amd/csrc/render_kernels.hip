@@ -334,15 +334,17 @@ __global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, D
     // XCDs, each with an L2 of its own: in row-major order every XCD would touch every part of
     // the scene.  For big frames the blocks of one XCD instead sweep a square region of tiles at a
     // time, so that the rays in flight on an XCD share the nodes and shapes in its L2.
-    uint32_t tile_x, tile_y;
+    uint32_t tile_x, tile_y, region = 0;
+    const unsigned long long started = f.region_cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (f.region_log2 == 0) {
         const uint32_t tiles_x = (f.width + 7u) >> 3;
         tile_x = blockIdx.x % tiles_x; tile_y = blockIdx.x / tiles_x;
     } else {
         const uint32_t per_log2 = 2u * f.region_log2, side_mask = (1u << f.region_log2) - 1u;
         const uint32_t xcd_slot = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        const uint32_t region = ((j >> per_log2) << 3) + xcd_slot, t = j & ((1u << per_log2) - 1u);
-        if (region >= f.n_regions) return;
+        const uint32_t turn = ((j >> per_log2) << 3) + xcd_slot, t = j & ((1u << per_log2) - 1u);
+        if (turn >= f.n_regions) return;
+        region = f.region_order ? f.region_order[turn] : turn;
         const uint32_t rx = region % f.regions_x, ry = region / f.regions_x;
         tile_x = (rx << f.region_log2) + (t & side_mask); tile_y = (ry << f.region_log2) + (t >> f.region_log2);
     }
@@ -440,6 +442,7 @@ __global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, D
         }
         out[pix] = quantise(cur);
     }
+    if (f.region_cost && lane == 0) atomicMax(&f.region_cost[region], (uint32_t)(__builtin_amdgcn_s_memrealtime() - started));
     if (COUNT) {
         unsigned long long v[6] = {cnt.nodes, cnt.prims, cnt.shadow, cnt.secondary, cnt.wave_node_iters, cnt.wave_prim_iters};
         for (int k = 0; k < 6; k++) {
@@ -448,6 +451,29 @@ __global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, D
             if (lane == 0 && s) atomicAdd(&counters[k], s);
         }
     }
+}
+
+// Regions by decreasing measured cost (bitonic sort of one workgroup in LDS; keys cost << 32 | ~index so that
+// equal costs keep index order).
+// `padded`: the power of two the n keys are padded to (with keys that sort last).
+__global__ __launch_bounds__(1024) void sort_regions_kernel(const uint32_t* __restrict__ cost, uint32_t n, uint32_t padded, uint32_t* __restrict__ order) {
+    __shared__ unsigned long long keys[MAX_SORTED_REGIONS];
+    for (uint32_t i = threadIdx.x; i < padded; i += blockDim.x)
+        keys[i] = i < n ? (((unsigned long long)cost[i] << 32) | (0xFFFFFFFFu - i)) : 0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= padded; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < padded; i += blockDim.x) {
+                const uint32_t partner = i ^ j;
+                if (partner > i) {
+                    const bool descending = (i & k) == 0;
+                    const unsigned long long a = keys[i], b = keys[partner];
+                    if (descending ? a < b : a > b) { keys[i] = b; keys[partner] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[i] = 0xFFFFFFFFu - (uint32_t)keys[i];
 }
 
 // Scatters the compact per-shard row buffers back into frame order on the gathering GPU.
@@ -469,18 +495,10 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     uint32_t tiles_x = (f->width + 7u) >> 3, tiles_y = (f->local_rows + 7u) >> 3;
     uint64_t blocks = (uint64_t)tiles_x * tiles_y;
     if (blocks == 0) return hipSuccess;
-    DevFrame placed = *f;
-    placed.region_log2 = 0; placed.regions_x = 0; placed.n_regions = 0;
-    // Regions of 16x16 tiles (128x128 pixels) once the frame has enough tiles to keep all XCDs busy
-    // region by region; larger regions lose more to imbalance between XCDs than they gain in L2.
-    const uint32_t region_log2 = blocks >= (1u << 14) ? 4u : 0u;
-    if (region_log2 > 0) {
-        const uint32_t side = 1u << region_log2;
-        const uint32_t rx = (tiles_x + side - 1) / side, ry = (tiles_y + side - 1) / side;
-        placed.region_log2 = region_log2; placed.regions_x = rx; placed.n_regions = rx * ry;
-        blocks = (((uint64_t)rx * ry + 7u) / 8u) * 8u * side * side;
+    if (f->region_log2 > 0) {             // the caller planned regions (see region_log2_for): whole regions for all 8 XCD slots
+        const uint64_t side = 1ull << f->region_log2;
+        blocks = (((uint64_t)f->n_regions + 7u) / 8u) * 8u * side * side;
     }
-    f = &placed;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((uint32_t)blocks), block(64);
     // One stack entry per tree level plus the sentinel; 8 KiB (32 entries) still lets 5 wavefronts per SIMD fit.
@@ -489,6 +507,14 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     const size_t lds_bytes = (size_t)entries * 64 * sizeof(uint32_t);
     if (count) hipLaunchKernelGGL((render_kernel<true>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters);
     else hipLaunchKernelGGL((render_kernel<false>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rtk_launch_sort_regions(const uint32_t* d_cost, uint32_t n, uint32_t* d_order, hipStream_t stream) {
+    if (n == 0 || n > MAX_SORTED_REGIONS) return hipErrorInvalidValue;
+    uint32_t padded = 2;
+    while (padded < n) padded <<= 1;
+    hipLaunchKernelGGL(sort_regions_kernel, dim3(1), dim3(padded < 1024 ? (padded < 64 ? 64 : padded) : 1024), 0, stream, d_cost, n, padded, d_order);
     return hipGetLastError();
 }
 
