@@ -137,7 +137,7 @@ def main():
     W, H = frame.width, frame.height
     # Work of this rank's shard (deterministic): instrumented kernel, outside the timed region.
     stride, local, gathered, full = renderer.buffers(W, H)
-    target = local[0] if use_dist else full
+    target = local[0] if use_dist else full[0]
     st = rt.render_tiles(frame, rank, world, target.data_ptr(), count_work=True)
     counts = torch.tensor([st["primary"], st["shadow"], st["secondary"], st["nodes_visited"], st["prims_tested"]],
                           dtype=torch.int64, device=renderer.device)
@@ -147,8 +147,7 @@ def main():
     primary, shadow, secondary, nodes, prims = (int(x) for x in counts.cpu().tolist())
 
     def sync_all():
-        rt.synchronize()
-        torch.cuda.synchronize(renderer.device)
+        torch.cuda.synchronize(renderer.device)        # every stream of the device, both lanes included
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize(renderer.device)
@@ -160,10 +159,12 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # HIP events on the stream the kernel is launched on (the library's stream, wrapped for torch).
-        ev[i][0].record(renderer.ext_stream)
+        # HIP events on the stream the kernel is launched on (the stream of the library's lane for this frame, wrapped
+        # for torch).  Consecutive frames are on different lanes and overlap, so these intervals overlap too.
+        lane_stream = renderer.ext_streams[renderer.next_lane()]
+        ev[i][0].record(lane_stream)
         out = renderer.render_frame(frame)
-        ev[i][1].record(renderer.ext_stream)
+        ev[i][1].record(lane_stream)
     renderer.flush()          # the last frame's gather and reassembly belong to the timed region
     sync_all()
     elapsed = time.perf_counter() - t0

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "rt_assemble_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "rt_compare_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]),
     "rt_pack_rgb": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rt_select_lane": (C.c_int, [C.c_int]),
     "rt_stream": (C.c_void_p, []),
     "rt_synchronize": (C.c_int, []),
     "rt_last_error": (C.c_char_p, []),
@@ -487,6 +488,11 @@ def compare_frames(ptr_a, size_a, ptr_b, size_b, diff_ptr=None):
 def pack_rgb(pixels_ptr, width, height, rgb_ptr):
     """0x??RRGGBB words -> R,G,B bytes, device to device, asynchronous on stream()."""
     _check(lib().rt_pack_rgb(C.c_void_p(pixels_ptr), width, height, C.c_void_p(rgb_ptr)))
+
+
+def select_lane(lane):
+    """Chooses which of the two lanes (stream + work buffers) the following calls use."""
+    _check(lib().rt_select_lane(int(lane)))
 
 
 def synchronize():

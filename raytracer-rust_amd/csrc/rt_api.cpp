@@ -2,7 +2,8 @@
 //
 // One process drives one GPU.  The scene lives in one device blob (layout.h) between
 // rt_upload_scene / rt_adopt_scene_blob and rt_shutdown; work buffers (frame, per-depth fold
-// records, counters) grow on demand and are reused across calls.  There is no CPU fallback:
+// records, counters) grow on demand and are reused across calls, one set per lane (a stream
+// with its own buffers: launches on the two lanes may overlap on the GPU).  There is no CPU fallback:
 // every entry point that needs the GPU fails with an error when HIP does.
 #include "../../include/rt_amd.h"
 
@@ -24,24 +25,34 @@ namespace {
 
 struct RegionKey { uint32_t width, height, shard, nshards, tile_rows; uint64_t scene; };   // what the regions of a launch depend on
 
+// A lane is a stream with the work buffers of the launches made on it.  Launches on one lane run in order;
+// launches on different lanes share nothing but the (read-only) scene and may overlap on the GPU, which is how
+// a caller that renders frame after frame hides the ramp-up and the drain of every launch (rt_select_lane).
+struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float4* d_fold = nullptr; size_t fold_cap = 0;          // records
+    unsigned long long* d_counters = nullptr;               // nodes, prims, shadow, secondary, wave-level passes
+    // order in which the tile regions of a launch are handed out, and what it was computed for
+    uint32_t* d_region_order = nullptr; uint32_t* d_region_cost = nullptr; uint32_t region_cap = 0;
+    RegionKey region_key{}; bool region_key_valid = false;
+};
+constexpr int N_LANES = 2;
+
 struct State {
     bool inited = false;
     int device = -1;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Lane lanes[N_LANES];
+    int lane = 0;                                           // the lane the next call uses
     void* d_blob = nullptr; size_t blob_bytes = 0; bool blob_owned = false; bool have_scene = false;
     rtl::BlobHeader hdr{};
     DevScene dsc{};
     rt_bvh_info info{};
-    uint32_t* d_out = nullptr; size_t out_cap = 0;          // pixels
-    float4* d_fold = nullptr; size_t fold_cap = 0;          // records
-    unsigned long long* d_counters = nullptr;               // nodes, prims, shadow, secondary
-    // order in which the tile regions of a launch are handed out, and what it was computed for
-    uint32_t* d_region_order = nullptr; uint32_t* d_region_cost = nullptr; uint32_t region_cap = 0;
-    RegionKey region_key{}; bool region_key_valid = false;
+    uint32_t* d_out = nullptr; size_t out_cap = 0;          // pixels (rt_render's frame before it is copied to the host)
     uint64_t scene_generation = 0;                          // bumped whenever another scene becomes resident
 };
 State g;
+Lane& cur() { return g.lanes[g.lane]; }
 
 int fail(const std::string& m) { rte::set_error(m); return 1; }
 int fail_hip(const char* what, hipError_t e) { rte::set_error(std::string(what) + ": " + hipGetErrorString(e)); return 1; }
@@ -51,6 +62,12 @@ int fail_hip(const char* what, hipError_t e) { rte::set_error(std::string(what) 
         hipError_t e_ = (expr);                                        \
         if (e_ != hipSuccess) return fail_hip(#expr, e_);              \
     } while (0)
+
+// Scene changes wait for the launches of every lane.
+int sync_lanes() {
+    for (Lane& l : g.lanes) if (l.stream) HIP_TRY(hipStreamSynchronize(l.stream));
+    return 0;
+}
 
 void release_scene() {
     if (g.d_blob && g.blob_owned) (void)hipFree(g.d_blob);
@@ -81,11 +98,11 @@ int check_frame(const rt_frame* f) {
 }
 
 int ensure_fold(size_t records) {
-    if (records <= g.fold_cap) return 0;
+    if (records <= cur().fold_cap) return 0;
     if (records * sizeof(float4) > (200ull << 30)) return fail("maxdepth x pixels needs more than 200 GiB of fold records");
-    if (g.d_fold) { (void)hipFree(g.d_fold); g.d_fold = nullptr; g.fold_cap = 0; }
-    HIP_TRY(hipMalloc((void**)&g.d_fold, records * sizeof(float4)));
-    g.fold_cap = records;
+    if (cur().d_fold) { (void)hipFree(cur().d_fold); cur().d_fold = nullptr; cur().fold_cap = 0; }
+    HIP_TRY(hipMalloc((void**)&cur().d_fold, records * sizeof(float4)));
+    cur().fold_cap = records;
     return 0;
 }
 
@@ -109,22 +126,22 @@ int plan_regions(const rt_frame& fr, DevFrame* f) {
     RegionKey key{};
     key.width = fr.width; key.height = fr.height;
     key.shard = f->shard; key.nshards = f->nshards; key.tile_rows = f->tile_rows; key.scene = g.scene_generation;
-    if (!g.region_key_valid || std::memcmp(&key, &g.region_key, sizeof(key)) != 0) {
-        if (f->n_regions > g.region_cap) {
-            if (g.d_region_order) { (void)hipFree(g.d_region_order); g.d_region_order = nullptr; g.region_cap = 0; }
-            if (g.d_region_cost) { (void)hipFree(g.d_region_cost); g.d_region_cost = nullptr; }
-            HIP_TRY(hipMalloc((void**)&g.d_region_order, (size_t)f->n_regions * sizeof(uint32_t)));
-            HIP_TRY(hipMalloc((void**)&g.d_region_cost, (size_t)f->n_regions * sizeof(uint32_t)));
-            g.region_cap = f->n_regions;
+    if (!cur().region_key_valid || std::memcmp(&key, &cur().region_key, sizeof(key)) != 0) {
+        if (f->n_regions > cur().region_cap) {
+            if (cur().d_region_order) { (void)hipFree(cur().d_region_order); cur().d_region_order = nullptr; cur().region_cap = 0; }
+            if (cur().d_region_cost) { (void)hipFree(cur().d_region_cost); cur().d_region_cost = nullptr; }
+            HIP_TRY(hipMalloc((void**)&cur().d_region_order, (size_t)f->n_regions * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&cur().d_region_cost, (size_t)f->n_regions * sizeof(uint32_t)));
+            cur().region_cap = f->n_regions;
         }
         // All costs equal: the sort leaves the regions in index order.
-        HIP_TRY(hipMemsetAsync(g.d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), g.stream));
-        HIP_TRY(rtk_launch_sort_regions(g.d_region_cost, f->n_regions, g.d_region_order, g.stream));
-        g.region_key = key; g.region_key_valid = true;
+        HIP_TRY(hipMemsetAsync(cur().d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), cur().stream));
+        HIP_TRY(rtk_launch_sort_regions(cur().d_region_cost, f->n_regions, cur().d_region_order, cur().stream));
+        cur().region_key = key; cur().region_key_valid = true;
     }
-    HIP_TRY(hipMemsetAsync(g.d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), g.stream));
-    f->region_order = g.d_region_order;
-    f->region_cost = g.d_region_cost;
+    HIP_TRY(hipMemsetAsync(cur().d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), cur().stream));
+    f->region_order = cur().d_region_order;
+    f->region_cost = cur().d_region_cost;
     return 0;
 }
 
@@ -150,21 +167,21 @@ int render_shard(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32
     size_t npix = (size_t)local_rows * frame->width;
     uint32_t levels = frame->maxdepth > 1 ? frame->maxdepth - 1 : 0;
     if (ensure_fold(npix * (size_t)levels)) return 1;
-    if (count_work) HIP_TRY(hipMemsetAsync(g.d_counters, 0, 8 * sizeof(unsigned long long), g.stream));
+    if (count_work) HIP_TRY(hipMemsetAsync(cur().d_counters, 0, 8 * sizeof(unsigned long long), cur().stream));
     if (plan_regions(*frame, &f)) return 1;
-    if (stats) HIP_TRY(hipEventRecord(g.ev0, g.stream));
-    HIP_TRY(rtk_launch_render(&g.dsc, &f, d_out, g.d_fold, g.d_counters, (int)g.hdr.max_depth, count_work, g.stream));
-    if (f.region_cost) HIP_TRY(rtk_launch_sort_regions(f.region_cost, f.n_regions, g.d_region_order, g.stream));
+    if (stats) HIP_TRY(hipEventRecord(cur().ev0, cur().stream));
+    HIP_TRY(rtk_launch_render(&g.dsc, &f, d_out, cur().d_fold, cur().d_counters, (int)g.hdr.max_depth, count_work, cur().stream));
+    if (f.region_cost) HIP_TRY(rtk_launch_sort_regions(f.region_cost, f.n_regions, cur().d_region_order, cur().stream));
     if (stats) {
-        HIP_TRY(hipEventRecord(g.ev1, g.stream));
-        HIP_TRY(hipEventSynchronize(g.ev1));
+        HIP_TRY(hipEventRecord(cur().ev1, cur().stream));
+        HIP_TRY(hipEventSynchronize(cur().ev1));
         float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, cur().ev0, cur().ev1));
         stats->kernel_ms = ms;
         stats->primary = npix;
         if (count_work) {
             unsigned long long c[8];
-            HIP_TRY(hipMemcpy(c, g.d_counters, sizeof(c), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(c, cur().d_counters, sizeof(c), hipMemcpyDeviceToHost));
             stats->nodes_visited = c[0]; stats->prims_tested = c[1]; stats->shadow = c[2]; stats->secondary = c[3];
             stats->box_passes = c[4]; stats->shape_passes = c[5];
         }
@@ -217,10 +234,13 @@ int rt_init(int device) {
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail("rt_init: no such HIP device");
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&g.ev0));
-    HIP_TRY(hipEventCreate(&g.ev1));
-    HIP_TRY(hipMalloc((void**)&g.d_counters, 8 * sizeof(unsigned long long)));
+    for (Lane& l : g.lanes) {
+        HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&l.ev0));
+        HIP_TRY(hipEventCreate(&l.ev1));
+        HIP_TRY(hipMalloc((void**)&l.d_counters, 8 * sizeof(unsigned long long)));
+    }
+    g.lane = 0;
     g.device = device; g.inited = true;
     return 0;
 }
@@ -233,12 +253,12 @@ int rt_upload_scene(const rt_scene* scene) {
     rtl::BlobHeader h; std::memcpy(&h, blob.data(), sizeof(h));
     if (!rtp::validate_header(h, blob.size(), &err)) return fail(err);
     HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (sync_lanes()) return 1;
     release_scene();
     HIP_TRY(hipMalloc(&g.d_blob, blob.size()));
     g.blob_owned = true; g.blob_bytes = blob.size();
-    HIP_TRY(hipMemcpyAsync(g.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(g.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, cur().stream));
+    HIP_TRY(hipStreamSynchronize(cur().stream));
     point_at_blob(g.d_blob, h);
     g.info = info;
     return 0;
@@ -259,9 +279,9 @@ int rt_upload_scene_ex(const rt_scene* scene, uint32_t flags) {
     in.lights = parts.lights.data(); in.n_lights = (uint32_t)parts.lights.size();
     in.finite_shading = parts.finite_shading; in.pad_abs = parts.pad_abs; in.depth_limit = rtp::TREE_DEPTH_LIMIT;
     HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (sync_lanes()) return 1;
     rtg::BuiltScene built{};
-    rtg::BuildStatus st = rtg::build_scene_on_gpu(in, g.stream, &built, &err);
+    rtg::BuildStatus st = rtg::build_scene_on_gpu(in, cur().stream, &built, &err);
     if (st == rtg::BUILD_TOO_DEEP) return rt_upload_scene(scene);                       // the host builder bounds the depth
     if (st != rtg::BUILD_OK) return fail(err);
     if (!rtp::validate_header(built.header, built.bytes, &err)) { (void)hipFree(built.d_blob); return fail(err); }
@@ -279,12 +299,12 @@ int rt_upload_scene_blob(const void* host_blob, size_t bytes) {
     if (!rtp::validate_blob((const uint8_t*)host_blob, bytes, &err)) return fail(err);
     rtl::BlobHeader h; std::memcpy(&h, host_blob, sizeof(h));
     HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (sync_lanes()) return 1;
     release_scene();
     HIP_TRY(hipMalloc(&g.d_blob, bytes));
     g.blob_owned = true; g.blob_bytes = bytes;
-    HIP_TRY(hipMemcpyAsync(g.d_blob, host_blob, bytes, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(g.d_blob, host_blob, bytes, hipMemcpyHostToDevice, cur().stream));
+    HIP_TRY(hipStreamSynchronize(cur().stream));
     g.info = rt_bvh_info{};
     point_at_blob(g.d_blob, h);
     return 0;
@@ -294,8 +314,8 @@ int rt_download_scene_blob(void* host_dst, size_t bytes) {
     if (!g.have_scene) return fail("no scene uploaded");
     if (!host_dst || bytes != g.blob_bytes) return fail("rt_download_scene_blob: destination must be exactly the blob size");
     HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(hipMemcpyAsync(host_dst, g.d_blob, bytes, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(host_dst, g.d_blob, bytes, hipMemcpyDeviceToHost, cur().stream));
+    HIP_TRY(hipStreamSynchronize(cur().stream));
     return 0;
 }
 
@@ -317,8 +337,8 @@ int rt_copy_scene_blob(void* device_dst, size_t bytes) {
     if (!g.have_scene) return fail("no scene uploaded");
     if (!device_dst || bytes != g.blob_bytes) return fail("rt_copy_scene_blob: destination must be exactly the blob size");
     HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(hipMemcpyAsync(device_dst, g.d_blob, bytes, hipMemcpyDeviceToDevice, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(device_dst, g.d_blob, bytes, hipMemcpyDeviceToDevice, cur().stream));
+    HIP_TRY(hipStreamSynchronize(cur().stream));
     return 0;
 }
 
@@ -326,7 +346,7 @@ int rt_adopt_scene_blob(void* device_ptr, size_t bytes) {
     if (!g.inited) return fail("rt_init has not been called");
     if (!device_ptr || bytes < sizeof(rtl::BlobHeader)) return fail("rt_adopt_scene_blob: buffer too small");
     HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    if (sync_lanes()) return 1;
     rtl::BlobHeader h;
     HIP_TRY(hipMemcpy(&h, device_ptr, sizeof(h), hipMemcpyDeviceToHost));
     std::string err;
@@ -370,8 +390,8 @@ int rt_render(const rt_frame* frame, uint32_t* out_pixels, rt_stats* stats, int 
     }
     rt_stats local{};
     if (render_shard(frame, 0, 1, 8, g.d_out, &local, count_work)) return 1;
-    HIP_TRY(hipMemcpyAsync(out_pixels, g.d_out, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(out_pixels, g.d_out, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, cur().stream));
+    HIP_TRY(hipStreamSynchronize(cur().stream));
     if (stats) {
         *stats = local;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -387,7 +407,7 @@ int rt_assemble_tiles(const uint32_t* d_gathered, uint32_t rows_per_shard_stride
     for (uint32_t s = 0; s < nshards; s++)
         if (rt_shard_rows(height, s, nshards, tile_rows) > rows_per_shard_stride) return fail("rt_assemble_tiles: stride smaller than a shard");
     HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(rtk_launch_assemble(d_gathered, rows_per_shard_stride, nshards, tile_rows, width, height, d_frame, g.stream));
+    HIP_TRY(rtk_launch_assemble(d_gathered, rows_per_shard_stride, nshards, tile_rows, width, height, d_frame, cur().stream));
     return 0;
 }
 
@@ -398,11 +418,11 @@ int rt_compare_frames(const uint32_t* d_a, uint32_t width_a, uint32_t height_a, 
     if (!d_a || !d_b) return fail("rt_compare_frames: NULL image");
     if (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)d_diff) & 15u) return fail("rt_compare_frames: buffers must be 16-byte aligned");
     HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(hipMemsetAsync(g.d_counters, 0, sizeof(unsigned long long), g.stream));
-    HIP_TRY(rtk_launch_compare(d_a, d_b, (size_t)width_a * height_a, d_diff, g.d_counters, g.stream));
+    HIP_TRY(hipMemsetAsync(cur().d_counters, 0, sizeof(unsigned long long), cur().stream));
+    HIP_TRY(rtk_launch_compare(d_a, d_b, (size_t)width_a * height_a, d_diff, cur().d_counters, cur().stream));
     unsigned long long c = 0;
-    HIP_TRY(hipMemcpyAsync(&c, g.d_counters, sizeof(c), hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpyAsync(&c, cur().d_counters, sizeof(c), hipMemcpyDeviceToHost, cur().stream));
+    HIP_TRY(hipStreamSynchronize(cur().stream));
     if (count) *count = c;
     return 0;
 }
@@ -412,31 +432,40 @@ int rt_pack_rgb(const uint32_t* d_pixels, uint32_t width, uint32_t height, uint8
     if (!d_pixels || !d_rgb) return fail("rt_pack_rgb: NULL buffer");
     if (((uintptr_t)d_pixels & 15u) || ((uintptr_t)d_rgb & 3u)) return fail("rt_pack_rgb: pixels must be 16-byte and rgb 4-byte aligned");
     HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(rtk_launch_pack_rgb(d_pixels, (size_t)width * height, d_rgb, g.stream));
+    HIP_TRY(rtk_launch_pack_rgb(d_pixels, (size_t)width * height, d_rgb, cur().stream));
     return 0;
 }
 
-void* rt_stream(void) { return (void*)g.stream; }
+int rt_select_lane(int lane) {
+    if (!g.inited) return fail("rt_init has not been called");
+    if (lane < 0 || lane >= N_LANES) return fail("rt_select_lane: there are two lanes, 0 and 1");
+    g.lane = lane;
+    return 0;
+}
+
+void* rt_stream(void) { return (void*)cur().stream; }
 
 int rt_synchronize(void) {
     if (!g.inited) return fail("rt_init has not been called");
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipStreamSynchronize(cur().stream));
     return 0;
 }
 
 void rt_shutdown(void) {
     if (!g.inited) return;
     (void)hipSetDevice(g.device);
-    (void)hipStreamSynchronize(g.stream);
+    (void)sync_lanes();
     release_scene();
     if (g.d_out) (void)hipFree(g.d_out);
-    if (g.d_fold) (void)hipFree(g.d_fold);
-    if (g.d_counters) (void)hipFree(g.d_counters);
-    if (g.d_region_order) (void)hipFree(g.d_region_order);
-    if (g.d_region_cost) (void)hipFree(g.d_region_cost);
-    if (g.ev0) (void)hipEventDestroy(g.ev0);
-    if (g.ev1) (void)hipEventDestroy(g.ev1);
-    if (g.stream) (void)hipStreamDestroy(g.stream);
+    for (Lane& l : g.lanes) {
+        if (l.d_fold) (void)hipFree(l.d_fold);
+        if (l.d_counters) (void)hipFree(l.d_counters);
+        if (l.d_region_order) (void)hipFree(l.d_region_order);
+        if (l.d_region_cost) (void)hipFree(l.d_region_cost);
+        if (l.ev0) (void)hipEventDestroy(l.ev0);
+        if (l.ev1) (void)hipEventDestroy(l.ev1);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
     g = State();
 }
 

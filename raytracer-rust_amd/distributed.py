@@ -7,9 +7,10 @@ rank 0 and replicated with one broadcast; every frame ends with one gather of th
 per-rank row buffers to rank 0, which scatters them back into frame order.  No other
 collective is involved.
 
-Frames are pipelined two deep: the gather of frame i runs on the collective's own stream while
-the kernel of frame i+1 renders into the other row buffer; rank 0 restores frame order of frame
-i when frame i+1 has been enqueued (or at flush()).
+Frames are pipelined two deep over the library's two lanes (a stream with its own work buffers
+each): frame i+1 is enqueued on the other lane than frame i, so its kernel fills the GPU while
+the kernel of frame i drains and the gather of frame i is in flight; rank 0 restores frame order
+of a frame when its lane is used again (or at flush()).
 
 The index arithmetic and the pipelining logic do not need a GPU: ShardedRenderer takes the two
 device operations (render my tiles, restore frame order) as callables, so the same class runs
@@ -59,10 +60,16 @@ class ShardedRenderer:
 
     render_rows(frame_desc, rank, world, tile_rows, out[stride, W])   enqueue this rank's tiles
     assemble(gathered[world, stride, W], frame_out[H, W], tile_rows)  restore frame order (rank 0)
-    stream_ctx()                                                      context manager entered around every enqueue
+    select_lane(lane)                                                 make `lane` (0 or 1) the one the two operations above use
+    stream_ctx(lane)                                                  context manager entered around everything enqueued for `lane`
+
+    Consecutive frames alternate between two lanes, each with its own stream and buffers, so the work of
+    frame i+1 does not wait for frame i: its kernel fills the GPU while the kernel of frame i drains, and the
+    gather of frame i overlaps it.  The tensor render_frame returns holds its frame once flush() has been called
+    (or two more frames have been enqueued) and the device has been synchronised.
     """
 
-    def __init__(self, device, render_rows, assemble, stream_ctx=None, tile_rows=TILE_ROWS, always_gather=False):
+    def __init__(self, device, render_rows, assemble, stream_ctx=None, tile_rows=TILE_ROWS, always_gather=False, select_lane=None):
         import contextlib
         import torch
         import torch.distributed as dist
@@ -72,60 +79,69 @@ class ShardedRenderer:
         self.device = device
         self.tile_rows = tile_rows
         self._render_rows, self._assemble = render_rows, assemble
-        self._stream_ctx = stream_ctx or contextlib.nullcontext
+        self._stream_ctx = stream_ctx or (lambda lane: contextlib.nullcontext())
+        self._select_lane = select_lane or (lambda lane: None)
         self._bufs = {}
-        self._pending = None            # (work, slot, W, H) of the frame whose gather is in flight
+        self._pending = [None, None]    # per lane: (work, W, H) of the frame whose gather is in flight
         self._slot = 0
         # A single rank normally renders straight into the frame; with always_gather it goes through
         # the same gather and reassembly as many ranks do (to rehearse that path on one GPU).
         self._collectives = self.world > 1 or (always_gather and dist.is_initialized())
 
     def buffers(self, width, height):
+        """(stride, local[2], gathered[2], frame[2]): one set per lane."""
         key = (width, height)
         if key not in self._bufs:
             torch = self.torch
             stride = max_shard_rows(height, self.world, self.tile_rows)
             local = [torch.zeros((stride, width), dtype=torch.int32, device=self.device) for _ in range(2)]
-            gathered, frame = [None, None], None
+            gathered, frame = [None, None], [None, None]
             if self.rank == 0:
-                frame = torch.zeros((height, width), dtype=torch.int32, device=self.device)
+                frame = [torch.zeros((height, width), dtype=torch.int32, device=self.device) for _ in range(2)]
                 if self._collectives:
                     gathered = [torch.zeros((self.world, stride, width), dtype=torch.int32, device=self.device) for _ in range(2)]
             self._bufs[key] = (stride, local, gathered, frame)
         return self._bufs[key]
 
-    def _complete(self):
-        """Rank 0: waits (on the stream, not the host) for the gather in flight and restores frame order."""
-        if self._pending is None:
+    def _complete(self, lane):
+        """Waits (on the lane's stream, not the host) for the gather in flight on `lane` and restores frame order on rank 0.
+        Must be called with the lane selected and its stream context entered."""
+        if self._pending[lane] is None:
             return
-        work, slot, W, H = self._pending
-        self._pending = None
+        work, W, H = self._pending[lane]
+        self._pending[lane] = None
         stride, local, gathered, frame = self.buffers(W, H)
         work.wait()
         if self.rank == 0:
-            self._assemble(gathered[slot], frame, self.tile_rows)
+            self._assemble(gathered[lane], frame[lane], self.tile_rows)
+
+    def next_lane(self):
+        return self._slot
 
     def render_frame(self, frame_desc):
-        """Enqueues one frame.  On rank 0 returns the tensor [H, W] (int32 view of 0xFFRRGGBB) that holds
-        the frame once flush() has been called (or one more frame has been enqueued) and the stream has drained."""
+        """Enqueues one frame on the next lane.  On rank 0 returns the tensor [H, W] (int32 view of 0xFFRRGGBB) of that frame."""
         W, H = frame_desc.width, frame_desc.height
         stride, local, gathered, frame = self.buffers(W, H)
-        with self._stream_ctx():
+        lane = self._slot
+        self._slot ^= 1
+        self._select_lane(lane)
+        with self._stream_ctx(lane):
             if not self._collectives:
-                self._render_rows(frame_desc, 0, 1, self.tile_rows, frame)
-                return frame
-            slot = self._slot
-            self._slot ^= 1
-            # the buffers of `slot` were last used two frames ago; that frame was completed one frame ago
-            self._render_rows(frame_desc, self.rank, self.world, self.tile_rows, local[slot])
-            work = self.dist.gather(local[slot], list(gathered[slot].unbind(0)) if self.rank == 0 else None, dst=0, async_op=True)
-            self._complete()                      # previous frame: its gather overlapped this frame's kernel launch
-            self._pending = (work, slot, W, H)
-        return frame
+                self._render_rows(frame_desc, 0, 1, self.tile_rows, frame[lane])
+                return frame[lane]
+            # the frame rendered on this lane two frames ago: its gather has had two kernels' time to finish
+            self._complete(lane)
+            self._render_rows(frame_desc, self.rank, self.world, self.tile_rows, local[lane])
+            work = self.dist.gather(local[lane], list(gathered[lane].unbind(0)) if self.rank == 0 else None, dst=0, async_op=True)
+            self._pending[lane] = (work, W, H)
+        return frame[lane]
 
     def flush(self):
-        with self._stream_ctx():
-            self._complete()
+        for lane in (self._slot, self._slot ^ 1):          # oldest first
+            self._select_lane(lane)
+            with self._stream_ctx(lane):
+                self._complete(lane)
+        self._select_lane(self._slot)
 
 
 def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gather=False, gpu_build=False):
@@ -136,7 +152,11 @@ def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gathe
     device = torch.device("cuda", device_index)
     torch.cuda.set_device(device)
     rt.init(device_index)
-    ext = torch.cuda.ExternalStream(rt.stream(), device=device)       # torch work is ordered on the library's stream
+    ext = []                                                           # torch work is ordered on the library's streams, one per lane
+    for lane in (0, 1):
+        rt.select_lane(lane)
+        ext.append(torch.cuda.ExternalStream(rt.stream(), device=device))
+    rt.select_lane(0)
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     info, keep = None, None
@@ -161,7 +181,7 @@ def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gathe
     def assemble(gathered, frame, rows):
         rt.assemble_tiles(gathered.data_ptr(), gathered.shape[1], gathered.shape[0], frame.shape[1], frame.shape[0], frame.data_ptr(), tile_rows=rows)
 
-    r = ShardedRenderer(device, render_rows, assemble, stream_ctx=lambda: torch.cuda.stream(ext), tile_rows=tile_rows,
-                        always_gather=always_gather)
-    r.ext_stream, r._keep_blob = ext, keep
+    r = ShardedRenderer(device, render_rows, assemble, stream_ctx=lambda lane: torch.cuda.stream(ext[lane]), tile_rows=tile_rows,
+                        always_gather=always_gather, select_lane=rt.select_lane)
+    r.ext_streams, r._keep_blob = ext, keep
     return r, info

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time of the 4K dragon frame cut into N shards, one launch per shard (diagnostic: what a rank of an
-N-GPU job spends in its kernel, and how much a launch loses to ramp-up and tail)."""
-import os, sys
+N-GPU job spends in its kernel), serial on one lane and pipelined over the two lanes."""
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
@@ -11,10 +11,19 @@ cfg = rt.ParsedConfigState().load_config_file(os.path.join(ROOT, "tests", "golde
 cfg.set_size(3840, 2160)
 rt.RayTracer(cfg)
 f = cfg.frame()
-buf = torch.zeros((2160, 3840), dtype=torch.int32, device="cuda:0")
+bufs = [torch.zeros((2160, 3840), dtype=torch.int32, device="cuda:0") for _ in range(2)]
 for n in (1, 2, 4, 8):
-    ts = []
+    ts, piped = [], []
     for s in range(n):
-        best = min(rt.render_tiles(f, s, n, buf.data_ptr(), want_stats=True)["kernel_ms"] for _ in range(5))
-        ts.append(best)
-    print(f"{n} shards: " + " ".join(f"{t:.3f}" for t in ts) + f"  sum {sum(ts):.3f} ms  max {max(ts):.3f} ms  -> ideal {n}-GPU speed-up {ts[0] if n == 1 else 0:.0f}", flush=True)
+        rt.select_lane(0)
+        ts.append(min(rt.render_tiles(f, s, n, bufs[0].data_ptr(), want_stats=True)["kernel_ms"] for _ in range(5)))
+    s = 0
+    for reps in (6, 40):            # warm both lanes' region orders, then time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            rt.select_lane(i & 1)
+            rt.render_tiles(f, s, n, bufs[i & 1].data_ptr())
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t0) / reps * 1e3
+    print(f"{n} shards: serial " + " ".join(f"{t:.3f}" for t in ts) + f"  (sum {sum(ts):.3f} ms);  shard 0 pipelined over two lanes: {per:.3f} ms per frame", flush=True)
