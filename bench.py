@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="frames in flight per GPU (default: 1 on one GPU, 2 with several)")
     args = ap.parse_args()
 
     # Libraries underneath (RCCL prints a version banner) write to file descriptor 1; the contract is
@@ -113,7 +114,7 @@ def main():
         cfg = rt.ParsedConfigState().load_config_file(SCENE)
         cfg.set_size(args.width, args.height)
     t_up = time.perf_counter()
-    renderer, bvh_info = shard_mod.gpu_renderer(rt, local_rank, scene=cfg.scene() if rank == 0 else None, always_gather=use_dist)
+    renderer, bvh_info = shard_mod.gpu_renderer(rt, local_rank, scene=cfg.scene() if rank == 0 else None, always_gather=use_dist, lanes=args.lanes or None)
     upload_s = time.perf_counter() - t_up
 
     # Every rank needs the frame constants; they are 22 numbers, computed on the host (tanf).
@@ -204,7 +205,8 @@ def main():
             "dtype": "f32",
             "data": "reference scene file final_avec_bonus.scene with the size line overridden to 3840 2160" if (W, H) == (WIDTH, HEIGHT)
                     else f"reference scene file final_avec_bonus.scene at {W}x{H}",
-            "config": {"workload": workload, "tile_rows": rt.TILE_ROWS, "sharding": f"interleaved row tiles over {world} GPU(s), gather to rank 0"},
+            "config": {"workload": workload, "tile_rows": rt.TILE_ROWS, "sharding": f"interleaved row tiles over {world} GPU(s), gather to rank 0",
+                       "frames_in_flight_per_gpu": renderer.lanes},
             "frames_per_s": args.steps / elapsed,
             "mrays_all_per_s": rays_all * args.steps / elapsed / 1e6,
             "rays_per_frame": {"primary": primary, "shadow": shadow, "reflection": secondary},

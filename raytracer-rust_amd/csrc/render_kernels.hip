@@ -463,13 +463,11 @@ __global__ __launch_bounds__(1024) void sort_regions_kernel(const uint32_t* __re
     __syncthreads();
     for (uint32_t k = 2; k <= padded; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < padded; i += blockDim.x) {
-                const uint32_t partner = i ^ j;
-                if (partner > i) {
-                    const bool descending = (i & k) == 0;
-                    const unsigned long long a = keys[i], b = keys[partner];
-                    if (descending ? a < b : a > b) { keys[i] = b; keys[partner] = a; }
-                }
+            for (uint32_t p = threadIdx.x; p < (padded >> 1); p += blockDim.x) {       // one compare-exchange per thread
+                const uint32_t i = ((p & ~(j - 1u)) << 1) | (p & (j - 1u)), partner = i | j;
+                const bool descending = (i & k) == 0;
+                const unsigned long long a = keys[i], b = keys[partner];
+                if (descending ? a < b : a > b) { keys[i] = b; keys[partner] = a; }
             }
             __syncthreads();
         }

@@ -69,7 +69,7 @@ class ShardedRenderer:
     (or two more frames have been enqueued) and the device has been synchronised.
     """
 
-    def __init__(self, device, render_rows, assemble, stream_ctx=None, tile_rows=TILE_ROWS, always_gather=False, select_lane=None):
+    def __init__(self, device, render_rows, assemble, stream_ctx=None, tile_rows=TILE_ROWS, always_gather=False, select_lane=None, lanes=None):
         import contextlib
         import torch
         import torch.distributed as dist
@@ -87,6 +87,10 @@ class ShardedRenderer:
         # A single rank normally renders straight into the frame; with always_gather it goes through
         # the same gather and reassembly as many ranks do (to rehearse that path on one GPU).
         self._collectives = self.world > 1 or (always_gather and dist.is_initialized())
+        # A single rank without collectives keeps to one lane unless asked otherwise: its launches then run one
+        # after the other, and a launch's duration is the time of a frame.
+        self.lanes = lanes if lanes is not None else (2 if self._collectives else 1)
+        assert self.lanes in (1, 2)
 
     def buffers(self, width, height):
         """(stride, local[2], gathered[2], frame[2]): one set per lane."""
@@ -123,7 +127,8 @@ class ShardedRenderer:
         W, H = frame_desc.width, frame_desc.height
         stride, local, gathered, frame = self.buffers(W, H)
         lane = self._slot
-        self._slot ^= 1
+        if self.lanes == 2:
+            self._slot ^= 1
         self._select_lane(lane)
         with self._stream_ctx(lane):
             if not self._collectives:
@@ -144,7 +149,7 @@ class ShardedRenderer:
         self._select_lane(self._slot)
 
 
-def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gather=False, gpu_build=False):
+def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gather=False, gpu_build=False, lanes=None):
     """ShardedRenderer on one MI355X: uploads (rank 0) or receives (other ranks) the scene and wires the
     library's tile rendering and frame assembly in.  Returns (renderer, bvh_info or None)."""
     import torch
@@ -182,6 +187,6 @@ def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gathe
         rt.assemble_tiles(gathered.data_ptr(), gathered.shape[1], gathered.shape[0], frame.shape[1], frame.shape[0], frame.data_ptr(), tile_rows=rows)
 
     r = ShardedRenderer(device, render_rows, assemble, stream_ctx=lambda lane: torch.cuda.stream(ext[lane]), tile_rows=tile_rows,
-                        always_gather=always_gather, select_lane=rt.select_lane)
+                        always_gather=always_gather, select_lane=rt.select_lane, lanes=lanes)
     r.ext_streams, r._keep_blob = ext, keep
     return r, info
