@@ -456,6 +456,35 @@ def test_tiny_and_empty_scenes(text):
         assert (got["primary"], got["shadow"], got["secondary"]) == (st["primary"], st["shadow"], st["secondary"])
 
 
+def test_two_lanes_render_different_frames_at_once():
+    """Launches on the two lanes overlap on the GPU and must not share work buffers: two different frames
+    enqueued back to back, several times over, equal their renders one at a time."""
+    import torch
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
+    cfg.set_size(1283, 721)
+    rt.RayTracer(cfg)
+    fa = cfg.frame()
+    fb = rt.frame_from_camera((9.0, 13.0, 12.0), (0.0, 5.0, -1.0), (0.0, 1.0, 0.0), 50.0, 1283, 721, 4, (0.0, 0.0, 0.0))
+    rt.select_lane(0)
+    want_a, _ = rt.render(fa)
+    want_b, _ = rt.render(fb)
+    assert not np.array_equal(want_a, want_b)
+    bufs = [torch.zeros((721, 1283), dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    try:
+        for _ in range(4):
+            rt.select_lane(0)
+            rt.render_tiles(fa, 0, 1, bufs[0].data_ptr())
+            rt.select_lane(1)
+            rt.render_tiles(fb, 0, 1, bufs[1].data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(bufs[0].cpu().numpy().view(np.uint32), want_a)
+        assert np.array_equal(bufs[1].cpu().numpy().view(np.uint32), want_b)
+        with pytest.raises(rt.RtError, match="two lanes"):
+            rt.select_lane(2)
+    finally:
+        rt.select_lane(0)
+
+
 def test_errors_are_reported_not_fatal():
     cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "test_file", "jalon3", "tp31.test"))
     rt.RayTracer.new(cfg)
