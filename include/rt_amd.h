@@ -13,7 +13,8 @@
  *   - the library owns device memory between rt_upload_scene and rt_shutdown;
  *   - every function returns 0 on success; on failure it returns non-zero and
  *     rt_last_error() describes it (the Err(String) of the reference); nothing aborts;
- *   - calls are blocking and come from one thread at a time, like the reference's render();
+ *   - calls come from one thread at a time and are blocking, like the reference's render(), except where a
+ *     function says it only enqueues work on rt_stream() (rt_render_tiles without stats, rt_assemble_tiles, rt_pack_rgb);
  *   - one process drives one GPU (rt_init(device)); multi-GPU jobs run one process per GPU
  *     and shard the frame by interleaved row tiles (rt_render_tiles).
  *   - pixels are 0xFFRRGGBB, row-major, first row on top (src/raytracer/raytracer.rs:85-91,
