@@ -20,6 +20,7 @@ struct SceneParts {
     uint32_t finite_shading;
     float pad_abs;             // absolute outward padding of every node box (the host builder's rule)
     uint32_t depth_limit;      // deepest tree the render kernels can traverse
+    uint32_t group_levels;     // levels of groups that get a split search (0 = as many as the builder has); above them the Morton-order tree stays
 };
 
 struct BuiltScene {
@@ -30,7 +31,7 @@ struct BuiltScene {
 enum BuildStatus { BUILD_OK = 0, BUILD_FAILED = 1, BUILD_TOO_DEEP = 2 };
 
 // Builds the tree on the GPU of the current device and assembles the scene blob in device memory.
-// BUILD_TOO_DEEP: the Morton-order tree is deeper than depth_limit (the caller falls back to the host builder).
+// BUILD_TOO_DEEP: the tree came out deeper than depth_limit (the caller falls back to the host builder).
 BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltScene* out, std::string* err);
 
 }  // namespace rtg

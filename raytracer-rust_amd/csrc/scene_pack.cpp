@@ -5,6 +5,7 @@
 // node pairs, reordered shape records, the material table and the lights into one buffer.
 #include "scene_pack.h"
 
+#include <omp.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -139,24 +140,46 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
     // the parser's current material (config_builder.rs:401-403): runs of equal materials are the rule,
     // so the table is only consulted where a run ends.
     std::unordered_map<MatKey, uint32_t, MatHash> mat_ids;
-    std::vector<uint32_t> tri_ids(s.ntri), sph_ids(s.nsph), pl_ids(s.npl);
+    NoInitVector<uint32_t> tri_ids(s.ntri), sph_ids(s.nsph), pl_ids(s.npl);
     auto assign_ids = [&](const float* mats, uint32_t n, uint32_t* ids) {
-        const float* prev = nullptr; uint32_t prev_id = 0;
-        for (uint32_t i = 0; i < n; i++) {
+        if (n == 0) return;
+        // where a run of equal materials starts: all threads, each over one stretch, stretches in order
+        const int nthreads = n > 100000 ? omp_get_max_threads() : 1;
+        std::vector<std::vector<uint32_t>> found((size_t)nthreads);
+#pragma omp parallel num_threads(nthreads)
+        {
+            const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+            const uint32_t a = (uint32_t)((uint64_t)n * (uint64_t)t / (uint64_t)nt), b = (uint32_t)((uint64_t)n * (uint64_t)(t + 1) / (uint64_t)nt);
+            if (t < nthreads)
+                for (uint32_t i = a; i < b; i++)
+                    if (i == 0 || std::memcmp(mats + 7 * (size_t)i, mats + 7 * (size_t)(i - 1), 28) != 0) found[(size_t)t].push_back(i);
+        }
+        std::vector<uint32_t> starts, start_id;
+        for (const auto& f : found) starts.insert(starts.end(), f.begin(), f.end());
+        start_id.reserve(starts.size());
+        for (uint32_t i : starts) {                          // in input order, so that the table does not depend on the threads
             const float* m = mats + 7 * (size_t)i;
-            if (!prev || std::memcmp(m, prev, 28) != 0) {
-                MatKey k; std::memcpy(k.w, m, sizeof(k.w));
-                auto it = mat_ids.find(k);
-                if (it == mat_ids.end()) {
-                    rtl::MaterialRec r{};
-                    r.diffuse[0] = m[0]; r.diffuse[1] = m[1]; r.diffuse[2] = m[2]; r.specular[0] = m[3]; r.specular[1] = m[4]; r.specular[2] = m[5];
-                    r.shininess = m[6];
-                    it = mat_ids.emplace(k, (uint32_t)out->mats.size()).first;
-                    out->mats.push_back(r);
-                }
-                prev = m; prev_id = it->second;
+            MatKey k; std::memcpy(k.w, m, sizeof(k.w));
+            auto it = mat_ids.find(k);
+            if (it == mat_ids.end()) {
+                rtl::MaterialRec r{};
+                r.diffuse[0] = m[0]; r.diffuse[1] = m[1]; r.diffuse[2] = m[2]; r.specular[0] = m[3]; r.specular[1] = m[4]; r.specular[2] = m[5];
+                r.shininess = m[6];
+                it = mat_ids.emplace(k, (uint32_t)out->mats.size()).first;
+                out->mats.push_back(r);
             }
-            ids[i] = prev_id;
+            start_id.push_back(it->second);
+        }
+        // every shape takes the id of the run it lies in
+        const int64_t CHUNK = 1 << 16;
+#pragma omp parallel for schedule(static) if (n > 100000)
+        for (int64_t c = 0; c < ((int64_t)n + CHUNK - 1) / CHUNK; c++) {
+            const uint32_t a = (uint32_t)(c * CHUNK), b = (uint32_t)std::min<int64_t>((int64_t)n, (c + 1) * CHUNK);
+            size_t run = (size_t)(std::upper_bound(starts.begin(), starts.end(), a) - starts.begin()) - 1;     // starts[0] == 0
+            for (uint32_t i = a; i < b; i++) {
+                if (run + 1 < starts.size() && starts[run + 1] == i) run++;
+                ids[i] = start_id[run];
+            }
         }
     };
     assign_ids(s.tri_mat, s.ntri, tri_ids.data());
@@ -169,51 +192,55 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
         const uint32_t i = j - s.ntri;
         return Flat{rtl::KIND_SPHERE, i, s.sph_order ? s.sph_order[i] : s.ntri + i, sph_ids[i]};
     };
-    out->tree.resize(bounded);
-#pragma omp parallel for schedule(static) if (bounded > 100000)
-    for (int64_t j = 0; j < (int64_t)bounded; j++) fill_record(s, flat_of((uint32_t)j), &out->tree[(size_t)j]);
-    if (!out->use_tree) { out->list.swap(out->tree); }      // a handful of shapes: all of them are tested for every ray
-    for (uint32_t i = 0; i < s.npl; i++) {
-        rtl::ShapeRec r; fill_record(s, Flat{rtl::KIND_PLANE, i, s.pl_order ? s.pl_order[i] : s.ntri + s.nsph + i, pl_ids[i]}, &r);
-        out->list.push_back(r);
-    }
-
-    // Extent of the bulk of the scene from a sample of the box centres (5th..95th percentile), for the
-    // absolute padding and for spotting the few shapes far larger than everything else.
     auto box_of = [](const rtl::ShapeRec& r, int k, float* lo, float* hi) {
         if ((r.kind_mat & 3u) == rtl::KIND_SPHERE) { *lo = r.q0[k] - r.q1[0]; *hi = r.q0[k] + r.q1[0]; }
         else { *lo = std::min(std::min(r.q0[k], r.q1[k]), r.q2[k]); *hi = std::max(std::max(r.q0[k], r.q1[k]), r.q2[k]); }
     };
-    const size_t ntree = out->tree.size();
+    // Extent of the bulk of the scene from a sample of the box centres (5th..95th percentile), for the
+    // absolute padding and for spotting the few shapes far larger than everything else.
+    const size_t ntree = out->use_tree ? bounded : 0;
     const size_t stride = std::max<size_t>(1, ntree / 65536);
     float extent = 0.0f;
     for (int k = 0; k < 3 && ntree > 0; k++) {
         std::vector<float> c;
-        for (size_t j = 0; j < ntree; j += stride) { float lo, hi; box_of(out->tree[j], k, &lo, &hi); c.push_back(0.5f * lo + 0.5f * hi); }
+        for (size_t j = 0; j < ntree; j += stride) {
+            rtl::ShapeRec r; fill_record(s, flat_of((uint32_t)j), &r);
+            float lo, hi; box_of(r, k, &lo, &hi); c.push_back(0.5f * lo + 0.5f * hi);
+        }
         const size_t a = c.size() / 20, b = c.size() - 1 - c.size() / 20;
         std::nth_element(c.begin(), c.begin() + (ptrdiff_t)a, c.end()); const float p5 = c[a];
         std::nth_element(c.begin(), c.begin() + (ptrdiff_t)b, c.end()); const float p95 = c[b];
         if (std::isfinite(p95 - p5)) extent = std::max(extent, p95 - p5);
     }
     out->pad_abs = extent * 4e-6f;
-    if (extent > 0.0f) {
-        std::vector<uint32_t> big;
-#pragma omp parallel for schedule(static) if (ntree > 100000)
-        for (int64_t j = 0; j < (int64_t)ntree; j++) {
+
+    // The records, and on the way the shapes far larger than the bulk.
+    out->tree.resize(bounded);
+    std::vector<uint32_t> big;
+#pragma omp parallel for schedule(static) if (bounded > 100000)
+    for (int64_t j = 0; j < (int64_t)bounded; j++) {
+        rtl::ShapeRec& r = out->tree[(size_t)j];
+        fill_record(s, flat_of((uint32_t)j), &r);
+        if (extent > 0.0f) {
             bool oversize = false;
-            for (int k = 0; k < 3; k++) { float lo, hi; box_of(out->tree[(size_t)j], k, &lo, &hi); oversize = oversize || hi - lo > 32.0f * extent; }
+            for (int k = 0; k < 3; k++) { float lo, hi; box_of(r, k, &lo, &hi); oversize = oversize || hi - lo > 32.0f * extent; }
             if (oversize) {
 #pragma omp critical
                 big.push_back((uint32_t)j);
             }
         }
-        if (!big.empty() && big.size() <= SMALL_SCENE && ntree - big.size() > SMALL_SCENE) {
-            std::sort(big.begin(), big.end());
-            for (size_t b = big.size(); b-- > 0;) {          // the order of the tree records is free: fill the hole with the last one
-                out->list.push_back(out->tree[big[b]]);
-                out->tree[big[b]] = out->tree.back();
-                out->tree.pop_back();
-            }
+    }
+    if (!out->use_tree) { out->list.assign(out->tree.begin(), out->tree.end()); out->tree.clear(); }      // a handful of shapes: all of them are tested for every ray
+    for (uint32_t i = 0; i < s.npl; i++) {
+        rtl::ShapeRec r; fill_record(s, Flat{rtl::KIND_PLANE, i, s.pl_order ? s.pl_order[i] : s.ntri + s.nsph + i, pl_ids[i]}, &r);
+        out->list.push_back(r);
+    }
+    if (!big.empty() && big.size() <= SMALL_SCENE && ntree - big.size() > SMALL_SCENE) {
+        std::sort(big.begin(), big.end());
+        for (size_t b = big.size(); b-- > 0;) {          // the order of the tree records is free: fill the hole with the last one
+            out->list.push_back(out->tree[big[b]]);
+            out->tree[big[b]] = out->tree.back();
+            out->tree.pop_back();
         }
     }
     std::sort(out->list.begin(), out->list.end(), [](const rtl::ShapeRec& a, const rtl::ShapeRec& b) { return a.order < b.order; });

@@ -3,7 +3,9 @@
 #define RT_SCENE_PACK_H
 
 #include <stdint.h>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -25,8 +27,19 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
 // records of the tree shapes in input order (triangles, then spheres), the always-tested list in
 // file order, the material table, the lights, and the padding rule of the node boxes.
 // use_tree is false for scenes so small that every shape goes to the list (then pack_scene is the way).
+// std::vector whose resize leaves plain-data elements unwritten: the big arrays here are filled right after by all
+// threads, and writing zeros into half a gigabyte first, from one thread, costs more than the fill.
+template <class T> struct NoInitAllocator : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAllocator<U>; };
+    template <class U, class... A> void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using NoInitVector = std::vector<T, NoInitAllocator<T>>;
+
 struct SceneParts {
-    std::vector<rtl::ShapeRec> tree, list;
+    NoInitVector<rtl::ShapeRec> tree;
+    std::vector<rtl::ShapeRec> list;
     std::vector<rtl::MaterialRec> mats;
     std::vector<rtl::LightRec> lights;
     uint32_t finite_shading = 1;

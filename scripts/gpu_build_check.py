@@ -13,10 +13,9 @@ def run(name, scene, frame):
     out = {}
     for gpu in (False, True):
         t0 = time.perf_counter(); info = rt.upload_scene(scene, gpu_build=gpu); t1 = time.perf_counter()
+        rt.validate_blob(rt.download_scene_blob())      # before any ray follows it
         img, st = rt.render(frame, count_work=True)
         ts = [rt.render(frame)[1]["kernel_ms"] for _ in range(4)]
-        blob = rt.download_scene_blob()
-        rt.validate_blob(blob)
         out[gpu] = img
         print(f"{name} {'gpu ' if gpu else 'host'} build: upload {1e3*(t1-t0):8.1f} ms  pairs {info['node_pairs']} leaves {info['leaves']} depth {info['max_depth']} "
               f"max leaf {info['max_leaf']} sah {info['sah_cost']:.1f}  kernel {min(ts):.3f} ms  boxes {st['nodes_visited']/1e6:.0f}M shapes {st['prims_tested']/1e6:.0f}M "
