@@ -3,22 +3,29 @@
 // The reference builds its bounding volume hierarchy on the CPU before it starts the clock
 // (Bvh::build_par, src/raytracer/raytracer.rs:32; main.rs:11-15).  The host builder of this
 // library (bvh_build.cpp, binned SAH) does the same in about a second per five million
-// triangles; this one takes milliseconds, at the price of a tree that is somewhat slower to
-// traverse (Morton-order radix tree instead of a surface-area split search).  Pixels do not
-// depend on the tree: it only culls (layout.h, render_kernels.hip).
+// triangles; this one takes tens of milliseconds, for a tree that is a few per cent slower to
+// traverse.  Pixels do not depend on the tree: it only culls (layout.h, render_kernels.hip).
 //
 // Steps, all on one stream, every kernel a plain data-parallel pass that reads only what earlier
 // launches wrote (no inter-block hand-offs inside a launch):
 //   1. boxes of the shapes (shape.rs:205-234), bounds of the boxes and of their centres
 //   2. 63-bit Morton code of every centre, radix sort (hipCUB)
-//   3. binary radix tree over the sorted codes (Karras 2012): node i covers a contiguous range
-//   4. bottom-up in rounds: a node whose children are finished takes the union of their boxes, its
-//      count, its SAH cost, whether it is better kept as one leaf (at most MAX_LEAF shapes), and
-//      the height of the tree below it.  One launch per round; a tree of height h needs h rounds.
-//   5. every node learns whether it survives (no ancestor became a leaf); survivors are numbered by
-//      a prefix sum
-//   6. survivors become 32-byte node pairs on the 16-bit scene grid, shapes are gathered into
-//      leaf order, both written straight into the final scene blob
+//   3. binary radix tree over the sorted codes (Karras 2012): node i covers a contiguous range.
+//      It is used for grouping only.
+//   4. groups: the largest radix nodes with at most GROUP shapes (level 1), then the largest with
+//      at most GROUP groups of the level before (levels 2..), until the root is a group; each
+//      level is one marking pass, one prefix sum and one listing pass over the positions, and one
+//      pass for the boxes of the groups
+//   5. from the top level down, one wavefront per group: binned surface-area split search over
+//      the group's items in LDS, node pairs written to temporary slots on the 16-bit scene grid,
+//      every item told where its own subtree has to be hooked in and how deep it sits; at level 1
+//      the items are shapes, leaves hold up to MAX_LEAF of them and the shapes of a group are
+//      put into leaf order
+//   6. used slots numbered by a prefix sum, node pairs and shape records written in final order
+//      straight into the scene blob
+// Radix nodes survive as tree nodes only above the last level of groups (never, unless the
+// scene has more than GROUP^LEVELS shapes, its shapes pile up on few Morton codes, or the
+// caller asked for fewer levels); their boxes come from bottom-up rounds, one launch per round.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <math.h>
