@@ -219,7 +219,10 @@ __device__ __forceinline__ void quantise_box(const Grid& g, const float* l, cons
 #endif
 constexpr uint32_t GROUP = RT_GROUP;
 constexpr int LEVELS = 4;               // most levels of groups
-constexpr int BINS = 16;
+#ifndef RT_BINS
+#define RT_BINS 16
+#endif
+constexpr int BINS = RT_BINS;
 
 struct ItemIndex {                 // items of one level: index of the item that holds a sorted position
     const uint32_t* incl;          // inclusive prefix sum of the item starts (item = incl[p] - 1); nullptr: every position is an item
@@ -411,10 +414,10 @@ __global__ __launch_bounds__(64) void build_groups(ItemList groups, ItemIndex in
                 }
             }
             __syncthreads();
-            // Candidate split after bin b of axis ax, one per lane.
+            // Candidate split after bin b of axis ax, spread over the lanes.
             float best = INFINITY; int best_id = -1;
-            if (lane < 3u * BINS) {
-                const uint32_t ax = lane / BINS, b = lane % BINS;
+            for (uint32_t cand = lane; cand < 3u * BINS; cand += 64) {
+                const uint32_t ax = cand / BINS, b = cand % BINS;
                 if (b + 1 < BINS && inv[ax] != 0.0f) {
                     float l0[3] = {INFINITY, INFINITY, INFINITY}, h0[3] = {-INFINITY, -INFINITY, -INFINITY}, l1[3] = {INFINITY, INFINITY, INFINITY}, h1[3] = {-INFINITY, -INFINITY, -INFINITY};
                     uint32_t n0 = 0, n1 = 0;
@@ -429,8 +432,8 @@ __global__ __launch_bounds__(64) void build_groups(ItemList groups, ItemIndex in
                     if (n0 && n1) {
                         const float a0 = (h0[0] - l0[0]) * (h0[1] - l0[1]) + (h0[1] - l0[1]) * (h0[2] - l0[2]) + (h0[2] - l0[2]) * (h0[0] - l0[0]);
                         const float a1 = (h1[0] - l1[0]) * (h1[1] - l1[1]) + (h1[1] - l1[1]) * (h1[2] - l1[2]) + (h1[2] - l1[2]) * (h1[0] - l1[0]);
-                        best = a0 * (float)n0 + a1 * (float)n1;
-                        if (best < INFINITY) best_id = (int)lane;              // overflow or NaN: not a candidate
+                        const float v = a0 * (float)n0 + a1 * (float)n1;
+                        if (v < best) { best = v; best_id = (int)cand; }       // overflow or NaN: not a candidate
                     }
                 }
             }
