@@ -51,13 +51,13 @@ struct Builder {
     uint32_t n;
     uint32_t depth_limit;
     float pad_abs;
-    std::vector<uint32_t> idx;             // permutation being partitioned
-    std::vector<float> ctr;                // n x 3 centroids
-    std::vector<rtl::NodePair> pairs;
+    rtu::NoInitVector<uint32_t> idx;       // permutation being partitioned
+    rtu::NoInitVector<float> ctr;          // n x 3 centroids
+    rtu::NoInitVector<rtl::NodePair> pairs;
     std::atomic<uint32_t> next_pair{0};
     std::atomic<uint32_t> n_leaves{0}, max_depth{0}, max_leaf{0};
 
-    std::vector<uint32_t> tmp;             // scratch of the parallel partition (same positions as idx)
+    rtu::NoInitVector<uint32_t> tmp;       // scratch of the parallel partition (same positions as idx)
     const uint32_t* perm = nullptr;        // builder position -> index of the caller's box (boxes are pre-sorted along a Morton curve)
 
     // Runs body(chunk, begin, end) over [first, first + count) in BIG_CHUNK pieces as OpenMP tasks and waits.
@@ -239,8 +239,16 @@ struct Builder {
         return mid;
     }
 
-    // Builds the subtree over idx[first, first+count) and returns its reference.
-    uint32_t build(uint32_t first, uint32_t count, uint32_t depth, const Box& node_box) {
+    static double area_of(const rtl::ChildBox& c) {
+        const double dx = (double)c.hi[0] - c.lo[0], dy = (double)c.hi[1] - c.lo[1], dz = (double)c.hi[2] - c.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+
+    // Builds the subtree over idx[first, first+count) and returns its reference; *cost receives the surface-area cost
+    // of the subtree times `area`, the surface measure of the box it is stored with (summed along the tree, so the
+    // value does not depend on how the threads interleaved).
+    uint32_t build(uint32_t first, uint32_t count, uint32_t depth, const Box& node_box, double area, double* cost) {
+        *cost = (double)COST_SHAPE * (double)count * area;          // as a leaf
         if (count == 1) return make_leaf(first, 1, depth);
         // Depth budget: a balanced subtree over `count` shapes needs ceil(log2(count / MAX_LEAF)) more levels.
         uint32_t need = 0; while (((uint64_t)rtl::MAX_LEAF << need) < count) need++;
@@ -251,34 +259,28 @@ struct Builder {
         uint32_t me = next_pair.fetch_add(1, std::memory_order_relaxed);
         uint32_t nl = mid - first, nr = first + count - mid;
         Box bl = bounds(first, nl), br = bounds(mid, nr);
+        rtl::NodePair& p = pairs[me];
+        write_child(p.c[0], bl, 0, 0);
+        write_child(p.c[1], br, 0, 0);
+        const double al = area_of(p.c[0]), ar = area_of(p.c[1]);
         uint32_t rl = 0, rr = 0;
+        double cl = 0.0, cr = 0.0;
         if (count >= PARALLEL_MIN) {
-#pragma omp task shared(rl) firstprivate(first, nl, depth, bl)
-            rl = build(first, nl, depth + 1, bl);
-#pragma omp task shared(rr) firstprivate(mid, nr, depth, br)
-            rr = build(mid, nr, depth + 1, br);
+#pragma omp task shared(rl, cl) firstprivate(first, nl, depth, bl, al)
+            rl = build(first, nl, depth + 1, bl, al, &cl);
+#pragma omp task shared(rr, cr) firstprivate(mid, nr, depth, br, ar)
+            rr = build(mid, nr, depth + 1, br, ar, &cr);
 #pragma omp taskwait
         } else {
-            rl = build(first, nl, depth + 1, bl);
-            rr = build(mid, nr, depth + 1, br);
+            rl = build(first, nl, depth + 1, bl, al, &cl);
+            rr = build(mid, nr, depth + 1, br, ar, &cr);
         }
-        rtl::NodePair& p = pairs[me];
-        write_child(p.c[0], bl, rl, (rl & rtl::REF_LEAF) ? (rl & 7u) + 1u : 0u);
-        write_child(p.c[1], br, rr, (rr & rtl::REF_LEAF) ? (rr & 7u) + 1u : 0u);
+        p.c[0].ref = rl; p.c[0].count = (rl & rtl::REF_LEAF) ? (rl & 7u) + 1u : 0u;
+        p.c[1].ref = rr; p.c[1].count = (rr & rtl::REF_LEAF) ? (rr & 7u) + 1u : 0u;
+        *cost = (double)COST_TRAVERSE * area + cl + cr;
         return me;
     }
 };
-
-double sah_of(const std::vector<rtl::NodePair>& pairs, uint32_t ref, double area_root, double area_self) {
-    if (ref & rtl::REF_LEAF) return COST_SHAPE * ((ref & 7u) + 1u) * area_self / area_root;
-    const rtl::NodePair& p = pairs[ref];
-    double c = COST_TRAVERSE * area_self / area_root;
-    for (int k = 0; k < 2; k++) {
-        double dx = (double)p.c[k].hi[0] - p.c[k].lo[0], dy = (double)p.c[k].hi[1] - p.c[k].lo[1], dz = (double)p.c[k].hi[2] - p.c[k].lo[2];
-        c += sah_of(pairs, p.c[k].ref, area_root, dx * dy + dy * dz + dz * dx);
-    }
-    return c;
-}
 
 }  // namespace
 
@@ -294,17 +296,19 @@ bool build_bvh(const float* lo, const float* hi, uint32_t n, uint32_t depth_limi
     }
     // Pre-sort the boxes along a Morton curve and build over the sorted copies: every subtree then works
     // on a compact stretch of memory instead of gathering its boxes from all over the input.
-    std::vector<uint32_t> perm(n);
-    std::vector<float> slo(3 * (size_t)n), shi(3 * (size_t)n);
+    rtu::NoInitVector<uint32_t> perm(n);
+    rtu::NoInitVector<float> slo(3 * (size_t)n), shi(3 * (size_t)n);
     {
-        double clo[3] = {0, 0, 0}, chi[3] = {0, 0, 0};
-        for (uint32_t i = 0; i < n; i++)
-            for (int k = 0; k < 3; k++) {
-                const double c = 0.5 * ((double)lo[3 * (size_t)i + k] + (double)hi[3 * (size_t)i + k]);
-                if (i == 0 || c < clo[k]) clo[k] = c;
-                if (i == 0 || c > chi[k]) chi[k] = c;
-            }
-        std::vector<uint64_t> keyed(n);
+        const double inf = std::numeric_limits<double>::infinity();
+        double clo0 = inf, clo1 = inf, clo2 = inf, chi0 = -inf, chi1 = -inf, chi2 = -inf;
+#pragma omp parallel for schedule(static) reduction(min : clo0, clo1, clo2) reduction(max : chi0, chi1, chi2) if (n >= BIG_NODE)
+        for (int64_t i = 0; i < (int64_t)n; i++) {
+            const double c0 = 0.5 * ((double)lo[3 * (size_t)i] + (double)hi[3 * (size_t)i]), c1 = 0.5 * ((double)lo[3 * (size_t)i + 1] + (double)hi[3 * (size_t)i + 1]),
+                         c2 = 0.5 * ((double)lo[3 * (size_t)i + 2] + (double)hi[3 * (size_t)i + 2]);
+            clo0 = std::min(clo0, c0); chi0 = std::max(chi0, c0); clo1 = std::min(clo1, c1); chi1 = std::max(chi1, c1); clo2 = std::min(clo2, c2); chi2 = std::max(chi2, c2);
+        }
+        const double clo[3] = {clo0, clo1, clo2}, chi[3] = {chi0, chi1, chi2};
+        rtu::NoInitVector<uint64_t> keyed(n);
 #pragma omp parallel for schedule(static) if (n >= BIG_NODE)
         for (int64_t i = 0; i < (int64_t)n; i++) {
             uint64_t code = 0;
@@ -340,11 +344,13 @@ bool build_bvh(const float* lo, const float* hi, uint32_t n, uint32_t depth_limi
     b.pairs.resize(n > 1 ? n - 1 : 1);
     Box root; root.reset();
     uint32_t root_ref = 0;
+    double root_cost = 0.0, root_area = 0.0;
 #pragma omp parallel
 #pragma omp single
     {
         root = b.bounds(0, n);
-        root_ref = b.build(0, n, 0, root);
+        root_area = root.half_area();
+        root_ref = b.build(0, n, 0, root, root_area, &root_cost);
     }
     b.pairs.resize(b.next_pair.load());
     out->pairs.swap(b.pairs);
@@ -353,8 +359,7 @@ bool build_bvh(const float* lo, const float* hi, uint32_t n, uint32_t depth_limi
     for (int64_t i = 0; i < (int64_t)n; i++) out->order[(size_t)i] = perm[b.idx[(size_t)i]];
     out->root_ref = root_ref;
     out->max_depth = b.max_depth.load(); out->max_leaf = b.max_leaf.load(); out->n_leaves = b.n_leaves.load();
-    double ar = root.half_area();
-    out->sah_cost = ar > 0.0 ? sah_of(out->pairs, root_ref, ar, ar) : 0.0;
+    out->sah_cost = root_area > 0.0 ? root_cost / root_area : 0.0;
     return true;
 }
 

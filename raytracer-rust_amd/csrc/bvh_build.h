@@ -7,12 +7,13 @@
 #include <vector>
 
 #include "layout.h"
+#include "no_init_vector.h"
 
 namespace rtb {
 
 struct BvhResult {
-    std::vector<rtl::NodePair> pairs;   // 64-byte child-pair records; pairs[root_ref] is the root when root_ref is inner
-    std::vector<uint32_t> order;        // tree-shape slot -> index of the input box (leaves are contiguous slots)
+    rtu::NoInitVector<rtl::NodePair> pairs;   // 64-byte child-pair records; pairs[root_ref] is the root when root_ref is inner
+    rtu::NoInitVector<uint32_t> order;        // tree-shape slot -> index of the input box (leaves are contiguous slots)
     uint32_t root_ref;                  // REF_EMPTY for no shapes, a leaf reference for a single-leaf tree
     uint32_t max_depth;                 // node pairs on the longest root-to-leaf path = traversal stack bound
     uint32_t max_leaf;

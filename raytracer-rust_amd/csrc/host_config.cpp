@@ -500,7 +500,7 @@ int rth_image_compare(const uint32_t* a, uint32_t wa, uint32_t ha, const uint32_
 
 int rth_pack_scene(const rt_scene* scene, void** blob, size_t* bytes, rt_bvh_info* info) {
     if (!scene || !blob || !bytes) return fail("rth_pack_scene: NULL argument");
-    std::vector<uint8_t> buf; std::string err; rt_bvh_info local{};
+    rtu::NoInitVector<uint8_t> buf; std::string err; rt_bvh_info local{};
     if (!rtp::pack_scene(*scene, &buf, &local, &err)) { rte::set_error(err); return 1; }
     void* p = std::malloc(buf.size());
     if (!p) return fail("out of memory");

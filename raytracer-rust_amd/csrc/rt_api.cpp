@@ -248,7 +248,7 @@ int rt_init(int device) {
 int rt_upload_scene(const rt_scene* scene) {
     if (!g.inited) return fail("rt_init has not been called");
     if (!scene) return fail("rt_scene is NULL");
-    std::vector<uint8_t> blob; rt_bvh_info info{}; std::string err;
+    rtu::NoInitVector<uint8_t> blob; rt_bvh_info info{}; std::string err;
     if (!rtp::pack_scene(*scene, &blob, &info, &err)) return fail(err);
     rtl::BlobHeader h; std::memcpy(&h, blob.data(), sizeof(h));
     if (!rtp::validate_header(h, blob.size(), &err)) return fail(err);

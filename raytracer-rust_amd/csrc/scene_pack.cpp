@@ -140,7 +140,7 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
     // the parser's current material (config_builder.rs:401-403): runs of equal materials are the rule,
     // so the table is only consulted where a run ends.
     std::unordered_map<MatKey, uint32_t, MatHash> mat_ids;
-    NoInitVector<uint32_t> tri_ids(s.ntri), sph_ids(s.nsph), pl_ids(s.npl);
+    rtu::NoInitVector<uint32_t> tri_ids(s.ntri), sph_ids(s.nsph), pl_ids(s.npl);
     auto assign_ids = [&](const float* mats, uint32_t n, uint32_t* ids) {
         if (n == 0) return;
         // where a run of equal materials starts: all threads, each over one stretch, stretches in order
@@ -260,7 +260,7 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
     return true;
 }
 
-bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info, std::string* err) {
+bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info* info, std::string* err) {
     auto t0 = std::chrono::steady_clock::now();
     SceneParts parts;
     if (!split_scene(s, &parts, err)) return false;
@@ -269,7 +269,7 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
 
     // Boxes of the tree shapes (shape.rs:208-234).
     const size_t nt = parts.tree.size();
-    std::vector<float> lo(3 * nt), hi(3 * nt);
+    rtu::NoInitVector<float> lo(3 * nt), hi(3 * nt);
     bool finite_boxes = true;
 #pragma omp parallel for schedule(static) reduction(&& : finite_boxes) if (nt > 100000)
     for (int64_t jj = 0; jj < (int64_t)nt; jj++) {
@@ -303,7 +303,13 @@ bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info
     h.off_lights = off; off = align256(off + (size_t)s.nlights * sizeof(rtl::LightRec));
     h.total_bytes = off;
     h.finite_shading = parts.finite_shading;
-    blob->assign(off, 0);
+    blob->resize(off);
+    {   // every section is written in full below; only the gaps up to the next 256-byte boundary need zeros
+        const size_t ends[5] = {h.off_nodes + (size_t)h.n_pairs * sizeof(rtl::QuantPair), h.off_tree_shapes + nt * sizeof(rtl::ShapeRec),
+                                h.off_list_shapes + list_shapes.size() * sizeof(rtl::ShapeRec), h.off_materials + mats.size() * sizeof(rtl::MaterialRec),
+                                h.off_lights + (size_t)s.nlights * sizeof(rtl::LightRec)};
+        for (size_t e : ends) std::memset(blob->data() + e, 0, align256(e) - e);
+    }
     // Quantise the (already padded) builder boxes outwards onto the 16-bit scene grid.
     {
         // The two children of the root bound everything below them.

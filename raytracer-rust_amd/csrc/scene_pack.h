@@ -10,6 +10,7 @@
 
 #include "../../include/rt_amd.h"
 #include "layout.h"
+#include "no_init_vector.h"
 
 namespace rtp {
 
@@ -21,24 +22,17 @@ constexpr uint32_t SMALL_SCENE = 8;
 // (64 entries) less the sentinel entry at its bottom.
 constexpr uint32_t TREE_DEPTH_LIMIT = 63;
 
-bool pack_scene(const rt_scene& s, std::vector<uint8_t>* blob, rt_bvh_info* info, std::string* err);
+
 
 // The same scene split into the parts of a blob without a tree, for the GPU tree builder: shape
 // records of the tree shapes in input order (triangles, then spheres), the always-tested list in
 // file order, the material table, the lights, and the padding rule of the node boxes.
 // use_tree is false for scenes so small that every shape goes to the list (then pack_scene is the way).
-// std::vector whose resize leaves plain-data elements unwritten: the big arrays here are filled right after by all
-// threads, and writing zeros into half a gigabyte first, from one thread, costs more than the fill.
-template <class T> struct NoInitAllocator : std::allocator<T> {
-    template <class U> struct rebind { using other = NoInitAllocator<U>; };
-    template <class U, class... A> void construct(U* p, A&&... a) {
-        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
-    }
-};
-template <class T> using NoInitVector = std::vector<T, NoInitAllocator<T>>;
+// The whole job of the host path: split, tree build (bvh_build.cpp), blob.  Padding between the sections of the blob is zero.
+bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info* info, std::string* err);
 
 struct SceneParts {
-    NoInitVector<rtl::ShapeRec> tree;
+    rtu::NoInitVector<rtl::ShapeRec> tree;
     std::vector<rtl::ShapeRec> list;
     std::vector<rtl::MaterialRec> mats;
     std::vector<rtl::LightRec> lights;
