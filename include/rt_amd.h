@@ -113,15 +113,12 @@ int rt_init(int device);
 int rt_upload_scene(const rt_scene* scene);
 
 /* rt_upload_scene with options.  RT_BUILD_ON_GPU builds the tree on the GPU instead of on the host: the
- * shapes are sorted along a Morton curve and grouped by the radix tree over the sorted codes (groups of up
- * to 256 shapes, then groups of up to 256 groups, ...), and every group gets the same binned surface-area
- * split search as the host builder's.  A tenth of a second instead of seconds for ten million triangles,
- * for a tree that is a few per cent slower to traverse.  The frame does not depend on the choice.  Falls
- * back to the host builder by itself for tiny scenes and for a tree deeper than the traversal stack.
- * RT_BUILD_GROUP_LEVELS(k), k = 1..4, or-ed in, stops the grouping after k levels and keeps the radix tree
- * above them (faster to build by little, slower to traverse; mainly for tests). */
+ * same binned surface-area split search from the root down, a tree level per round of kernels while the
+ * nodes are large and a wavefront per node in LDS once they hold at most 256 shapes.  A tenth of a second
+ * instead of a second and a half for ten million triangles, for a tree of the same quality.  The frame
+ * does not depend on the choice.  Falls back to the host builder by itself for tiny scenes and for a tree
+ * deeper than the traversal stack. */
 #define RT_BUILD_ON_GPU 1u
-#define RT_BUILD_GROUP_LEVELS(k) (((uint32_t)(k) & 7u) << 8)
 int rt_upload_scene_ex(const rt_scene* scene, uint32_t flags);
 
 int rt_get_bvh_info(rt_bvh_info* out);

@@ -367,10 +367,9 @@ def shutdown():
 BUILD_ON_GPU = 1
 
 
-def upload_scene(scene, gpu_build=False, group_levels=0):
-    """RayTracer::new: tree build (host split search, or on the GPU with gpu_build=True) + upload.
-    group_levels (1..4, GPU build only): RT_BUILD_GROUP_LEVELS of rt_amd.h."""
-    _check(lib().rt_upload_scene_ex(C.byref(scene), (BUILD_ON_GPU | ((group_levels & 7) << 8)) if gpu_build else 0))
+def upload_scene(scene, gpu_build=False):
+    """RayTracer::new: tree build (split search on the host, or on the GPU with gpu_build=True) + upload."""
+    _check(lib().rt_upload_scene_ex(C.byref(scene), BUILD_ON_GPU if gpu_build else 0))
     info = rt_bvh_info()
     _check(lib().rt_get_bvh_info(C.byref(info)))
     return info.as_dict()

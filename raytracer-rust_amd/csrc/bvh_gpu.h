@@ -20,7 +20,6 @@ struct SceneParts {
     uint32_t finite_shading;
     float pad_abs;             // absolute outward padding of every node box (the host builder's rule)
     uint32_t depth_limit;      // deepest tree the render kernels can traverse
-    uint32_t group_levels;     // levels of groups that get a split search (0 = as many as the builder has); above them the Morton-order tree stays
 };
 
 struct BuiltScene {

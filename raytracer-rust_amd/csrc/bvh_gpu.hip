@@ -2,30 +2,30 @@
 //
 // The reference builds its bounding volume hierarchy on the CPU before it starts the clock
 // (Bvh::build_par, src/raytracer/raytracer.rs:32; main.rs:11-15).  The host builder of this
-// library (bvh_build.cpp, binned SAH) does the same in about a second per five million
-// triangles; this one takes tens of milliseconds, for a tree that is a few per cent slower to
-// traverse.  Pixels do not depend on the tree: it only culls (layout.h, render_kernels.hip).
+// library (bvh_build.cpp) runs a binned surface-area split search from the root down, about a
+// second per eight million triangles; this file runs the same search on the GPU in a tenth of
+// that.  Pixels do not depend on the tree: it only culls (layout.h, render_kernels.hip).
 //
 // Steps, all on one stream, every kernel a plain data-parallel pass that reads only what earlier
 // launches wrote (no inter-block hand-offs inside a launch):
 //   1. boxes of the shapes (shape.rs:205-234), bounds of the boxes and of their centres
-//   2. 63-bit Morton code of every centre, radix sort (hipCUB)
-//   3. binary radix tree over the sorted codes (Karras 2012): node i covers a contiguous range.
-//      It is used for grouping only.
-//   4. groups: the largest radix nodes with at most GROUP shapes (level 1), then the largest with
-//      at most GROUP groups of the level before (levels 2..), until the root is a group; each
-//      level is one marking pass, one prefix sum and one listing pass over the positions, and one
-//      pass for the boxes of the groups
-//   5. from the top level down, one wavefront per group: binned surface-area split search over
-//      the group's items in LDS, node pairs written to temporary slots on the 16-bit scene grid,
-//      every item told where its own subtree has to be hooked in and how deep it sits; at level 1
-//      the items are shapes, leaves hold up to MAX_LEAF of them and the shapes of a group are
-//      put into leaf order
-//   6. used slots numbered by a prefix sum, node pairs and shape records written in final order
+//   2. 63-bit Morton code of every centre, radix sort (hipCUB): the order the shapes start in, so
+//      that what lies together in space lies together in memory
+//   3. large nodes (more than GROUP shapes), one tree level per round: every node is cut into
+//      chunks of CHUNK shapes, a workgroup per chunk bins its shapes (3 axes x BINS bins in LDS,
+//      merged into the node's bins with atomics), a wavefront per node picks the cheapest split
+//      and turns the chunks' bin counts into the places their shapes go to, a workgroup per chunk
+//      moves them (stable) and collects the boxes of the two sides, a thread per node writes the
+//      node pair and hands its children to the next round or, once they have at most GROUP
+//      shapes, to step 4
+//   4. small nodes: a wavefront per group of at most GROUP shapes runs the same search down to
+//      the leaves with everything in LDS, and puts the shapes of its group into leaf order
+//   5. used slots numbered by a prefix sum; node pairs and shape records written in final order
 //      straight into the scene blob
-// Radix nodes survive as tree nodes only above the last level of groups (never, unless the
-// scene has more than GROUP^LEVELS shapes, its shapes pile up on few Morton codes, or the
-// caller asked for fewer levels); their boxes come from bottom-up rounds, one launch per round.
+// Node pairs are written on the 16-bit scene grid from the start, into temporary slots; whoever
+// makes a node is told which child reference of which pair waits for it (`link`) and how many
+// pairs lie above it (`depth`, which is what bounds the tree: halving by position takes over
+// where the split search would break the traversal stack's depth).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <math.h>
@@ -43,7 +43,6 @@ namespace rtg {
 namespace {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr uint32_t LEAF_BIT = 0x80000000u;     // child reference: bit 31 set = shape at that sorted position
 constexpr float COST_BOX = 1.0f, COST_SHAPE = 1.0f;   // relative cost of one box-pair step and one shape test in the render kernel
 
 // Monotone map float -> uint32 so that unsigned min/max atomics order floats.
@@ -139,57 +138,8 @@ __global__ __launch_bounds__(256) void gather_boxes(const float4* __restrict__ l
     slo[p] = lo[i]; shi[p] = hi[i];
 }
 
-// Length of the common prefix of the keys at sorted positions i and j (equal keys: continue with the positions themselves).
-__device__ __forceinline__ int common_prefix(const uint64_t* __restrict__ keys, uint32_t n, int i, int j) {
-    if (j < 0 || j >= (int)n) return -1;
-    const uint64_t a = keys[i], b = keys[j];
-    if (a != b) return __clzll((long long)(a ^ b));
-    return 64 + __clz((int)((uint32_t)i ^ (uint32_t)j));
-}
-
-struct Topology {
-    uint32_t* left; uint32_t* right;       // children of internal node i (LEAF_BIT | sorted position, or internal index)
-    uint32_t* parent;                      // parent of internal node i (NONE for the root, node 0)
-    uint32_t* leaf_parent;                 // internal node above the shape at a sorted position
-    uint32_t* first; uint32_t* last;       // sorted positions covered by internal node i
-};
-
-__global__ __launch_bounds__(256) void radix_tree(const uint64_t* __restrict__ keys, uint32_t n, Topology t) {
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= (int)n - 1) return;
-    // Direction of the range and its other end (Karras 2012, section 3).
-    const int d = common_prefix(keys, n, i, i + 1) - common_prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
-    const int dmin = common_prefix(keys, n, i, i - d);
-    int lmax = 2;
-    while (common_prefix(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
-    int l = 0;
-    for (int s = lmax >> 1; s >= 1; s >>= 1)
-        if (common_prefix(keys, n, i, i + (l + s) * d) > dmin) l += s;
-    const int j = i + l * d;
-    // Split position: the highest differing bit inside the range.
-    const int dnode = common_prefix(keys, n, i, j);
-    int sp = 0;
-    for (int s = (l + 1) >> 1;; s = (s + 1) >> 1) {
-        if (common_prefix(keys, n, i, i + (sp + s) * d) > dnode) sp += s;
-        if (s <= 1) break;
-    }
-    const int gamma = i + sp * d + min(d, 0);
-    const int lo = min(i, j), hi = max(i, j);
-    const uint32_t lc = lo == gamma ? (LEAF_BIT | (uint32_t)gamma) : (uint32_t)gamma;
-    const uint32_t rc = hi == gamma + 1 ? (LEAF_BIT | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
-    t.left[i] = lc; t.right[i] = rc; t.first[i] = (uint32_t)lo; t.last[i] = (uint32_t)hi;
-    if (!(lc & LEAF_BIT)) t.parent[lc] = (uint32_t)i; else t.leaf_parent[lc & ~LEAF_BIT] = (uint32_t)i;
-    if (!(rc & LEAF_BIT)) t.parent[rc] = (uint32_t)i; else t.leaf_parent[rc & ~LEAF_BIT] = (uint32_t)i;
-    if (i == 0) t.parent[0] = NONE;
-}
-
-struct NodeData {
-    float4* lo; float4* hi;                // box of internal node i (union of the shape boxes below it, not padded); only for nodes above the groups
-    uint32_t* done;                        // round in which i was finished (0 = not yet)
-};
-
-__device__ __forceinline__ float half_area(float4 l, float4 h) {
-    const float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z;
+__device__ __forceinline__ float half_area3(const float* l, const float* h) {
+    const float dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
     return dx * dy + dy * dz + dz * dx;
 }
 
@@ -207,162 +157,360 @@ __device__ __forceinline__ void quantise_box(const Grid& g, const float* l, cons
     }
 }
 
-// The radix tree only groups; the tree that is rendered comes from a surface-area split search inside the groups.
-// Level 1: the items are the shapes, a group is a largest radix node with at most GROUP shapes (or a single shape
-// hanging directly under a larger node).  Level k + 1: the items are the groups of level k, a group is a largest
-// radix node with at most GROUP of them.  The levels are built from the top down, each group handing to each of its
-// items the place its subtree has to be hooked into (`link`) and the number of node pairs above it (`depth`).  What is
-// left above the last level (radix nodes with more than GROUP items of it; none for scenes of up to GROUP^LEVELS
-// shapes spread evenly) stays as the radix tree made it.
-#ifndef RT_GROUP
-#define RT_GROUP 256
-#endif
-constexpr uint32_t GROUP = RT_GROUP;
-constexpr int LEVELS = 4;               // most levels of groups
-#ifndef RT_BINS
-#define RT_BINS 16
-#endif
-constexpr int BINS = RT_BINS;
+constexpr uint32_t GROUP = 256;          // most shapes of a node that one wavefront finishes in LDS
+constexpr uint32_t CHUNK = 2048;         // shapes of a large node that one workgroup bins and moves
+constexpr int BINS = 16;                 // 8, 16 and 32 bins per axis give the same frame times within 1 %
 
-struct ItemIndex {                 // items of one level: index of the item that holds a sorted position
-    const uint32_t* incl;          // inclusive prefix sum of the item starts (item = incl[p] - 1); nullptr: every position is an item
-    __device__ __forceinline__ uint32_t of(uint32_t p) const { return incl ? incl[p] - 1u : p; }
-    __device__ __forceinline__ uint32_t under(const Topology& t, uint32_t i) const { return of(t.last[i]) - of(t.first[i]) + 1u; }
+struct Bins {                            // per axis and bin: box of the shapes whose centre falls into it (ordered uints), their number
+    uint32_t lo[3][BINS][3], hi[3][BINS][3], cnt[3][BINS];
 };
 
-// Starts of the groups of this level = starts of the items of the next.
-__global__ __launch_bounds__(256) void mark_groups(uint32_t n, Topology t, ItemIndex items, uint32_t* __restrict__ start) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n - 1) {
-        const uint32_t up = t.parent[i];
-        if (items.under(t, i) <= GROUP && (up == NONE || items.under(t, up) > GROUP)) start[t.first[i]] = 1u;
-    }
-    if (i < n && items.under(t, t.leaf_parent[i]) > GROUP) start[i] = 1u;      // a shape (then always an item by itself) directly under a larger node
+__device__ __forceinline__ int bin_of(float lo, float hi, float origin, float scale) {
+    const int b = (int)((0.5f * lo + 0.5f * hi - origin) * scale);
+    return min(max(b, 0), BINS - 1);
 }
 
-struct ItemList {                  // items of one level above the shapes, in the order of their sorted positions
-    uint32_t* first; uint32_t* last;        // sorted positions covered
-    float4* lo; float4* hi;                 // box, not padded
-    uint32_t* link;                         // temporary slot * 2 + side of the child reference that waits for this item's subtree (NONE: the root)
-    uint32_t* depth;                        // node pairs above it
-    uint32_t count;
-};
-
-__global__ __launch_bounds__(256) void list_groups(uint32_t n, Topology t, ItemIndex items, ItemIndex groups, ItemList out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n - 1) {
-        const uint32_t up = t.parent[i];
-        if (items.under(t, i) <= GROUP && (up == NONE || items.under(t, up) > GROUP)) {
-            const uint32_t j = groups.of(t.first[i]);
-            out.first[j] = t.first[i]; out.last[j] = t.last[i]; out.link[j] = NONE; out.depth[j] = 0u;
-        }
-    }
-    if (i < n && items.under(t, t.leaf_parent[i]) > GROUP) {
-        const uint32_t j = groups.of(i);
-        out.first[j] = i; out.last[j] = i; out.link[j] = NONE; out.depth[j] = 0u;
+__device__ __forceinline__ void bin_scales(const float* clo, const float* chi, float* inv) {
+    for (int k = 0; k < 3; k++) {
+        inv[k] = chi[k] > clo[k] ? (float)BINS * 0.999999f / (chi[k] - clo[k]) : 0.0f;
+        if (!(inv[k] < INFINITY)) inv[k] = 0.0f;
     }
 }
 
-// Box of every group from the boxes of its items, one wavefront per group.
-__global__ __launch_bounds__(256) void group_boxes(ItemList groups, ItemIndex index, const float4* __restrict__ ilo, const float4* __restrict__ ihi) {
-    const uint32_t c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    if (c >= groups.count) return;
-    const uint32_t a = index.of(groups.first[c]), b = index.of(groups.last[c]);
-    float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t j = a + lane; j <= b && j - a < GROUP; j += 64) {
-        const float4 x = ilo[j], y = ihi[j];
-        l[0] = fminf(l[0], x.x); l[1] = fminf(l[1], x.y); l[2] = fminf(l[2], x.z); h[0] = fmaxf(h[0], y.x); h[1] = fmaxf(h[1], y.y); h[2] = fmaxf(h[2], y.z);
-    }
-    for (int off = 32; off > 0; off >>= 1)
-        for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], __shfl_xor(l[k], off, 64)); h[k] = fmaxf(h[k], __shfl_xor(h[k], off, 64)); }
-    if (lane == 0) { groups.lo[c] = make_float4(l[0], l[1], l[2], 0.0f); groups.hi[c] = make_float4(h[0], h[1], h[2], 0.0f); }
-}
-
-// Radix nodes above the last level of groups: how many there are, and their boxes bottom-up in rounds (one launch
-// per round; a node is finished when its children were finished in earlier rounds; groups and shapes are finished
-// from the start).
-__global__ __launch_bounds__(256) void count_upper(uint32_t n, Topology t, ItemIndex items, uint32_t* __restrict__ remaining) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long m = __ballot(i < n - 1 && items.under(t, i) > GROUP);
-    if (m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) atomicAdd(remaining, (uint32_t)__popcll(m));
-}
-
-__global__ __launch_bounds__(256) void fit_upper_round(uint32_t n, uint32_t round, Topology t, NodeData d, const float4* __restrict__ slo, const float4* __restrict__ shi,
-                                                       ItemIndex items, ItemIndex groups, ItemList top, uint32_t* __restrict__ remaining) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool finished = false;
-    if (i < n - 1 && items.under(t, i) > GROUP && d.done[i] == 0) {
-        const uint32_t c[2] = {t.left[i], t.right[i]};
-        float4 l[2], h[2];
-        bool ready = true;
-        for (int k = 0; k < 2; k++) {
-            if (c[k] & LEAF_BIT) { const uint32_t p = c[k] & ~LEAF_BIT; l[k] = slo[p]; h[k] = shi[p]; }
-            else if (items.under(t, c[k]) <= GROUP) { const uint32_t j = groups.of(t.first[c[k]]); l[k] = top.lo[j]; h[k] = top.hi[j]; }
-            else {
-                const uint32_t r = d.done[c[k]];
-                if (r == 0 || r >= round) { ready = false; l[k] = h[k] = make_float4(0, 0, 0, 0); }   // not finished before this launch
-                else { l[k] = d.lo[c[k]]; h[k] = d.hi[c[k]]; }
+// Cheapest split "bins 0..b of axis ax to the left" over all axes with a usable scale, candidates spread over the
+// lanes of the calling wavefront.  Every lane returns the same: *best = sum over the sides of area x count (INFINITY
+// when nothing separates), result = ax * BINS + b or -1.
+__device__ int best_split(const Bins& bins, const float* inv, uint32_t lane, float* best_out) {
+    float best = INFINITY; int best_id = -1;
+    for (uint32_t cand = lane; cand < 3u * BINS; cand += 64) {
+        const uint32_t ax = cand / BINS, b = cand % BINS;
+        if (b + 1 < BINS && inv[ax] != 0.0f) {
+            float l0[3] = {INFINITY, INFINITY, INFINITY}, h0[3] = {-INFINITY, -INFINITY, -INFINITY}, l1[3] = {INFINITY, INFINITY, INFINITY}, h1[3] = {-INFINITY, -INFINITY, -INFINITY};
+            uint32_t n0 = 0, n1 = 0;
+            for (uint32_t q = 0; q < (uint32_t)BINS; q++) {
+                const uint32_t c = bins.cnt[ax][q];
+                if (c == 0u) continue;
+                for (int k = 0; k < 3; k++) {
+                    const float l = unordered(bins.lo[ax][q][k]), h = unordered(bins.hi[ax][q][k]);
+                    if (q <= b) { l0[k] = fminf(l0[k], l); h0[k] = fmaxf(h0[k], h); } else { l1[k] = fminf(l1[k], l); h1[k] = fmaxf(h1[k], h); }
+                }
+                if (q <= b) n0 += c; else n1 += c;
+            }
+            if (n0 && n1) {
+                const float v = half_area3(l0, h0) * (float)n0 + half_area3(l1, h1) * (float)n1;
+                if (v < best) { best = v; best_id = (int)cand; }       // overflow or NaN: not a candidate
             }
         }
-        if (ready) {
-            d.lo[i] = make_float4(fminf(l[0].x, l[1].x), fminf(l[0].y, l[1].y), fminf(l[0].z, l[1].z), 0.0f);
-            d.hi[i] = make_float4(fmaxf(h[0].x, h[1].x), fmaxf(h[0].y, h[1].y), fmaxf(h[0].z, h[1].z), 0.0f);
-            d.done[i] = round;
-            finished = true;
-        }
     }
-    // One update of the counter per wavefront.
-    const unsigned long long m = __ballot(finished);
-    if (m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) atomicSub(remaining, (uint32_t)__popcll(m));
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(best_id, off, 64);
+        if (oi >= 0 && (best_id < 0 || ob < best || (ob == best && oi < best_id))) { best = ob; best_id = oi; }
+    }
+    *best_out = __shfl(best, 0, 64);
+    return __shfl(best_id, 0, 64);                                     // one decision for the whole wavefront
 }
 
-struct BuildStats { uint32_t n_leaves, max_leaf, max_depth, root_ref; unsigned long long cost_micro; };
+// Halving by position instead of a split search: when the levels a balanced subtree still needs (leaves of
+// MAX_LEAF shapes) would otherwise not fit under the depth limit.
+__device__ __forceinline__ bool must_halve(uint32_t depth, uint32_t count, uint32_t depth_limit) {
+    uint32_t need = 0;
+    while ((rtl::MAX_LEAF << need) < count) need++;
+    return depth + need + 1u >= depth_limit;
+}
 
-// Temporary node pairs.  A group whose first item has index a puts its k-th pair into slot base(level) + a + k
-// (a group of m items makes at most m - 1 pairs); `used` marks the slots that hold a pair.
+struct BuildStats { uint32_t n_leaves, max_leaf, max_depth, root_ref; unsigned long long cost_micro; uint32_t n_groups, pad; };
+
+// Temporary node pairs.  A group whose first shape sits at position a puts its k-th pair into slot a + k (a group of
+// m shapes makes at most m - 1 pairs); the large nodes of a round use one slot each behind those.  `used` marks the
+// slots that hold a pair.
 struct TempTree {
     rtl::QuantPair* pairs; uint32_t* used;
-    uint32_t* order_out;          // sorted position -> shape index, after the level-1 groups reordered their ranges
+    uint32_t* order_out;          // final position -> shape index
 };
 
 __device__ __forceinline__ void hook(const TempTree& tmp, BuildStats* stats, uint32_t link, uint32_t ref) {
     if (link == NONE) stats->root_ref = ref; else tmp.pairs[link >> 1].c[link & 1u].ref = ref;
 }
 
-// Binned surface-area split search over the items of one group, one wavefront per group, everything in LDS.
-// The rules of the host builder (bvh_build.cpp): cost of a split = area-weighted weights of the two sides; with shapes
-// as items a node of at most MAX_LEAF of them stays a leaf when that is cheaper; halving by position (Morton order)
-// when the depth budget runs out or no split separates anything.  SHAPES: level 1, leaves hold shapes and the shapes of
-// the group are put into leaf order.  Otherwise a leaf is one item and receives link and depth for the level below.
-template <bool SHAPES>
-__global__ __launch_bounds__(64) void build_groups(ItemList groups, ItemIndex index, const float4* __restrict__ ilo, const float4* __restrict__ ihi,
-                                                   const uint32_t* __restrict__ item_first, const uint32_t* __restrict__ item_last,
-                                                   uint32_t* __restrict__ item_link, uint32_t* __restrict__ item_depth, uint32_t slot_base,
-                                                   const uint32_t* __restrict__ order_in, Grid g, TempTree tmp, uint32_t depth_limit, uint32_t reserve,
+// ------------------------------------------------------------------------------------------------ large nodes
+struct BigNode {
+    uint32_t first, count;             // its shapes: positions [first, first + count) of the permutation
+    uint32_t link, depth;
+    uint32_t clo[3], chi[3];           // bounds of the centres of its shapes (ordered uints)
+};
+
+struct SideBounds { uint32_t lo[3], hi[3], clo[3], chi[3]; };    // box and centre bounds of one side of a split (ordered uints)
+
+struct Split {
+    int axis;                          // -1: halves by position
+    float origin, scale; uint32_t bin; // shapes with bin_of(axis) <= bin go left
+    uint32_t n_left;
+};
+
+struct Level {                         // work arrays of one round; n_nodes nodes, their chunks numbered node after node
+    const BigNode* nodes; uint32_t n_nodes;
+    const uint32_t* chunk_off;         // first chunk of node i; [n_nodes] = number of chunks
+    Bins* bins;                        // per node
+    uint32_t* chunk_cnt;               // per chunk: 3 x BINS counts
+    uint32_t* chunk_left;              // per chunk: shapes that go left in the chunks of the same node before it
+    Split* split;                      // per node
+    SideBounds* sides;                 // per node x 2
+    uint32_t* n_big;                   // per node: children that are large nodes again
+};
+
+__global__ __launch_bounds__(256) void level_begin(Level lv, uint32_t* __restrict__ n_chunks_of) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < lv.n_nodes) n_chunks_of[t] = (lv.nodes[t].count + CHUNK - 1) / CHUNK;
+    if (t == lv.n_nodes) n_chunks_of[t] = 0u;
+    // bins and side bounds start empty
+    const uint32_t per_node = 3u * BINS;
+    if (t < lv.n_nodes * per_node) {
+        const uint32_t i = t / per_node, ax = (t % per_node) / BINS, b = t % BINS;
+        for (int k = 0; k < 3; k++) { lv.bins[i].lo[ax][b][k] = 0xFFFFFFFFu; lv.bins[i].hi[ax][b][k] = 0u; }
+        lv.bins[i].cnt[ax][b] = 0u;
+    }
+    if (t < lv.n_nodes * 2u)
+        for (int k = 0; k < 3; k++) { lv.sides[t].lo[k] = lv.sides[t].clo[k] = 0xFFFFFFFFu; lv.sides[t].hi[k] = lv.sides[t].chi[k] = 0u; }
+}
+
+// Node that chunk c belongs to: the last i with chunk_off[i] <= c.
+__device__ __forceinline__ uint32_t node_of_chunk(const Level& lv, uint32_t c) {
+    uint32_t a = 0, b = lv.n_nodes;          // chunk_off[a] <= c < chunk_off[b]
+    while (b - a > 1u) { const uint32_t m = (a + b) >> 1; if (lv.chunk_off[m] <= c) a = m; else b = m; }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void bin_chunks(Level lv, const uint32_t* __restrict__ idx, const float4* __restrict__ slo, const float4* __restrict__ shi,
+                                                  uint32_t depth_limit) {
+    __shared__ Bins bins;
+    __shared__ uint32_t s_node;
+    const uint32_t c = blockIdx.x;
+    if (c >= lv.chunk_off[lv.n_nodes]) return;
+    if (threadIdx.x == 0) s_node = node_of_chunk(lv, c);
+    for (uint32_t j = threadIdx.x; j < 3u * BINS; j += blockDim.x) {
+        const uint32_t ax = j / BINS, b = j % BINS;
+        for (int k = 0; k < 3; k++) { bins.lo[ax][b][k] = 0xFFFFFFFFu; bins.hi[ax][b][k] = 0u; }
+        bins.cnt[ax][b] = 0u;
+    }
+    __syncthreads();
+    const uint32_t i = s_node;
+    const BigNode nd = lv.nodes[i];
+    if (must_halve(nd.depth, nd.count, depth_limit)) return;          // no split search for this node
+    const uint32_t s = nd.first + (c - lv.chunk_off[i]) * CHUNK, e = min(nd.first + nd.count, s + CHUNK);
+    float clo[3], chi[3], inv[3];
+    for (int k = 0; k < 3; k++) { clo[k] = unordered(nd.clo[k]); chi[k] = unordered(nd.chi[k]); }
+    bin_scales(clo, chi, inv);
+    for (uint32_t p = s + threadIdx.x; p < e; p += blockDim.x) {
+        const uint32_t sh = idx[p];
+        const float4 l = slo[sh], h = shi[sh];
+        const float bl[3] = {l.x, l.y, l.z}, bh[3] = {h.x, h.y, h.z};
+        for (int ax = 0; ax < 3; ax++) {
+            if (inv[ax] == 0.0f) continue;
+            const int b = bin_of(bl[ax], bh[ax], clo[ax], inv[ax]);
+            for (int k = 0; k < 3; k++) { atomicMin(&bins.lo[ax][b][k], ordered(bl[k])); atomicMax(&bins.hi[ax][b][k], ordered(bh[k])); }
+            atomicAdd(&bins.cnt[ax][b], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < 3u * BINS; j += blockDim.x) {
+        const uint32_t ax = j / BINS, b = j % BINS, n = bins.cnt[ax][b];
+        lv.chunk_cnt[(size_t)c * (3u * BINS) + j] = n;
+        if (n) {
+            for (int k = 0; k < 3; k++) { atomicMin(&lv.bins[i].lo[ax][b][k], bins.lo[ax][b][k]); atomicMax(&lv.bins[i].hi[ax][b][k], bins.hi[ax][b][k]); }
+            atomicAdd(&lv.bins[i].cnt[ax][b], n);
+        }
+    }
+}
+
+// One wavefront per node: the split, and for every chunk of the node how many shapes of the chunks before it go left.
+__global__ __launch_bounds__(256) void split_nodes(Level lv, uint32_t depth_limit) {
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (i >= lv.n_nodes) return;
+    const BigNode nd = lv.nodes[i];
+    Split sp; sp.axis = -1; sp.origin = 0.0f; sp.scale = 0.0f; sp.bin = 0u; sp.n_left = nd.count / 2u;
+    if (!must_halve(nd.depth, nd.count, depth_limit)) {
+        float clo[3], chi[3], inv[3], best;
+        for (int k = 0; k < 3; k++) { clo[k] = unordered(nd.clo[k]); chi[k] = unordered(nd.chi[k]); }
+        bin_scales(clo, chi, inv);
+        const int id = best_split(lv.bins[i], inv, lane, &best);
+        if (id >= 0) { sp.axis = id / BINS; sp.bin = (uint32_t)(id % BINS); sp.origin = clo[sp.axis]; sp.scale = inv[sp.axis]; }
+    }
+    const uint32_t c0 = lv.chunk_off[i], c1 = lv.chunk_off[i + 1];
+    uint32_t running = 0;
+    for (uint32_t base = c0; base < c1; base += 64) {
+        const uint32_t c = base + lane;
+        uint32_t mine = 0;
+        if (c < c1) {
+            if (sp.axis >= 0) {
+                const uint32_t* cnt = lv.chunk_cnt + (size_t)c * (3u * BINS) + (uint32_t)sp.axis * BINS;
+                for (uint32_t b = 0; b <= sp.bin; b++) mine += cnt[b];
+            } else {                                                    // halves by position
+                const uint32_t s = (c - c0) * CHUNK, e = min(nd.count, s + CHUNK), half = nd.count / 2u;
+                mine = min(e, half) - min(s, half);
+            }
+        }
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
+        if (c < c1) lv.chunk_left[c] = running + incl - mine;
+        running += __shfl(incl, 63, 64);
+    }
+    if (sp.axis >= 0) sp.n_left = running;
+    if (lane == 0) {
+        lv.split[i] = sp;
+        lv.n_big[i] = (sp.n_left > GROUP ? 1u : 0u) + (nd.count - sp.n_left > GROUP ? 1u : 0u);
+        if (i == 0) lv.n_big[lv.n_nodes] = 0u;
+    }
+}
+
+// A workgroup per chunk moves the chunk's shapes to their side of the split, keeping their order, and collects the
+// boxes and centre bounds of the two sides.
+__global__ __launch_bounds__(256) void move_chunks(Level lv, const uint32_t* __restrict__ idx, uint32_t* __restrict__ idx_out, const float4* __restrict__ slo,
+                                                   const float4* __restrict__ shi) {
+    __shared__ uint32_t s_node, s_wave[4][2];
+    __shared__ SideBounds s_side[2];
+    const uint32_t c = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (c >= lv.chunk_off[lv.n_nodes]) return;
+    if (threadIdx.x == 0) s_node = node_of_chunk(lv, c);
+    if (threadIdx.x < 2)
+        for (int k = 0; k < 3; k++) { s_side[threadIdx.x].lo[k] = s_side[threadIdx.x].clo[k] = 0xFFFFFFFFu; s_side[threadIdx.x].hi[k] = s_side[threadIdx.x].chi[k] = 0u; }
+    __syncthreads();
+    const uint32_t i = s_node;
+    const BigNode nd = lv.nodes[i];
+    const Split sp = lv.split[i];
+    const uint32_t s = nd.first + (c - lv.chunk_off[i]) * CHUNK, e = min(nd.first + nd.count, s + CHUNK);
+    uint32_t at_left = nd.first + lv.chunk_left[c];                                  // next free place on either side
+    uint32_t at_right = nd.first + sp.n_left + ((s - nd.first) - lv.chunk_left[c]);
+    for (uint32_t base = s; base < e; base += blockDim.x) {
+        const uint32_t p = base + threadIdx.x;
+        bool left = false, right = false; uint32_t sh = 0;
+        float bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
+        if (p < e) {
+            sh = idx[p];
+            const float4 l = slo[sh], h = shi[sh];
+            bl[0] = l.x; bl[1] = l.y; bl[2] = l.z; bh[0] = h.x; bh[1] = h.y; bh[2] = h.z;
+            left = sp.axis >= 0 ? (uint32_t)bin_of(bl[sp.axis], bh[sp.axis], sp.origin, sp.scale) <= sp.bin : p - nd.first < sp.n_left;
+            right = !left;
+        }
+        const unsigned long long ml = __ballot(left), mr = __ballot(right), below = (1ull << lane) - 1ull;
+        if (lane == 0) { s_wave[wave][0] = (uint32_t)__popcll(ml); s_wave[wave][1] = (uint32_t)__popcll(mr); }
+        __syncthreads();
+        uint32_t before_l = 0, before_r = 0, all_l = 0, all_r = 0;
+        for (uint32_t w = 0; w < 4; w++) {
+            if (w < wave) { before_l += s_wave[w][0]; before_r += s_wave[w][1]; }
+            all_l += s_wave[w][0]; all_r += s_wave[w][1];
+        }
+        if (left) idx_out[at_left + before_l + (uint32_t)__popcll(ml & below)] = sh;
+        if (right) idx_out[at_right + before_r + (uint32_t)__popcll(mr & below)] = sh;
+        at_left += all_l; at_right += all_r;
+        if (p < e) {
+            SideBounds& sb = s_side[left ? 0 : 1];
+            for (int k = 0; k < 3; k++) {
+                const uint32_t ctr = ordered(0.5f * bl[k] + 0.5f * bh[k]);
+                atomicMin(&sb.lo[k], ordered(bl[k])); atomicMax(&sb.hi[k], ordered(bh[k])); atomicMin(&sb.clo[k], ctr); atomicMax(&sb.chi[k], ctr);
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) {
+        const uint32_t side = threadIdx.x / 3, k = threadIdx.x % 3;
+        SideBounds& out = lv.sides[2u * i + side];
+        if (s_side[side].lo[k] <= s_side[side].hi[k]) {                // the chunk had shapes on this side
+            atomicMin(&out.lo[k], s_side[side].lo[k]); atomicMax(&out.hi[k], s_side[side].hi[k]);
+            atomicMin(&out.clo[k], s_side[side].clo[k]); atomicMax(&out.chi[k], s_side[side].chi[k]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_chunks(Level lv, const uint32_t* __restrict__ from, uint32_t* __restrict__ to) {
+    __shared__ uint32_t s_node;
+    const uint32_t c = blockIdx.x;
+    if (c >= lv.chunk_off[lv.n_nodes]) return;
+    if (threadIdx.x == 0) s_node = node_of_chunk(lv, c);
+    __syncthreads();
+    const BigNode nd = lv.nodes[s_node];
+    const uint32_t s = nd.first + (c - lv.chunk_off[s_node]) * CHUNK, e = min(nd.first + nd.count, s + CHUNK);
+    for (uint32_t p = s + threadIdx.x; p < e; p += blockDim.x) to[p] = from[p];
+}
+
+struct GroupList {                     // nodes of at most GROUP shapes, in the order they came up
+    uint32_t* first; uint32_t* count; uint32_t* link; uint32_t* depth;
+};
+
+// A thread per node: its node pair, and its children handed on.
+__global__ __launch_bounds__(256) void emit_nodes(Level lv, const uint32_t* __restrict__ next_index, BigNode* __restrict__ next, GroupList groups, uint32_t slot_base,
+                                                  Grid g, TempTree tmp, float root_area, BuildStats* __restrict__ stats) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lv.n_nodes) return;
+    const BigNode nd = lv.nodes[i];
+    const Split sp = lv.split[i];
+    const uint32_t slot = slot_base + i;
+    rtl::QuantPair pair;
+    float ul[3] = {INFINITY, INFINITY, INFINITY}, uh[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t big_at = next_index[i];
+    for (uint32_t side = 0; side < 2u; side++) {
+        const SideBounds& sb = lv.sides[2u * i + side];
+        float l[3], h[3];
+        for (int k = 0; k < 3; k++) { l[k] = unordered(sb.lo[k]); h[k] = unordered(sb.hi[k]); ul[k] = fminf(ul[k], l[k]); uh[k] = fmaxf(uh[k], h[k]); }
+        quantise_box(g, l, h, &pair.c[side]);
+        pair.c[side].ref = rtl::REF_EMPTY;                             // hooked in when the child is made
+        const uint32_t first = side == 0 ? nd.first : nd.first + sp.n_left, count = side == 0 ? sp.n_left : nd.count - sp.n_left;
+        if (count > GROUP) {
+            BigNode ch; ch.first = first; ch.count = count; ch.link = slot * 2u + side; ch.depth = nd.depth + 1u;
+            for (int k = 0; k < 3; k++) { ch.clo[k] = sb.clo[k]; ch.chi[k] = sb.chi[k]; }
+            next[big_at++] = ch;
+        } else {
+            const uint32_t j = atomicAdd(&stats->n_groups, 1u);
+            groups.first[j] = first; groups.count[j] = count; groups.link[j] = slot * 2u + side; groups.depth[j] = nd.depth + 1u;
+        }
+    }
+    tmp.pairs[slot] = pair;
+    tmp.used[slot] = 1u;
+    hook(tmp, stats, nd.link, slot);
+    if (root_area > 0.0f) atomicAdd(&stats->cost_micro, (unsigned long long)((double)COST_BOX * (double)half_area3(ul, uh) / (double)root_area * 1e6));
+}
+
+__global__ __launch_bounds__(256) void iota(uint32_t* __restrict__ a, uint32_t* __restrict__ b, uint32_t n) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) { a[p] = p; b[p] = p; }
+}
+
+// Shape boxes and shape indices in the order of the permutation the large nodes left behind.
+__global__ __launch_bounds__(256) void gather_by_index(const uint32_t* __restrict__ idx, uint32_t n, const float4* __restrict__ slo, const float4* __restrict__ shi,
+                                                       const uint32_t* __restrict__ order, float4* __restrict__ plo, float4* __restrict__ phi, uint32_t* __restrict__ order_p) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t sh = idx[p];
+    plo[p] = slo[sh]; phi[p] = shi[sh]; order_p[p] = order[sh];
+}
+
+// ------------------------------------------------------------------------------------------------ small nodes
+// Binned surface-area split search over the shapes of one group, one wavefront per group, everything in LDS.
+// The rules of the host builder (bvh_build.cpp): cost of a split = area-weighted counts of the two sides; a node of
+// at most MAX_LEAF shapes stays a leaf when that is cheaper; halving by position when the depth budget runs out or no
+// split separates anything.  The shapes of the group are put into leaf order.
+__global__ __launch_bounds__(64) void build_groups(GroupList groups, uint32_t n_groups, const float4* __restrict__ plo, const float4* __restrict__ phi,
+                                                   const uint32_t* __restrict__ order_in, Grid g, TempTree tmp, uint32_t depth_limit,
                                                    float root_area, BuildStats* __restrict__ stats) {
     __shared__ float blo[3][GROUP], bhi[3][GROUP];
     __shared__ uint16_t perm[GROUP], scratch[GROUP];
-    __shared__ uint8_t weight[SHAPES ? 1 : GROUP];
-    __shared__ uint32_t bin_lo[3][BINS][3], bin_hi[3][BINS][3], bin_cnt[3][BINS];
+    __shared__ Bins bins;
     // Pending nodes.  The smaller child is always taken next, so every node that waits is at least as large as all
     // that is above it on the stack: at most log2(GROUP) + 1 wait at any time.
     constexpr int STACK = 40;
     __shared__ uint16_t task_start[STACK], task_count[STACK], task_depth[STACK];
     __shared__ uint32_t task_link[STACK];
     const uint32_t c = blockIdx.x, lane = threadIdx.x;
-    if (c >= groups.count) return;
-    const uint32_t a = index.of(groups.first[c]), m_all = index.of(groups.last[c]) - a + 1u;
-    if (m_all > GROUP) return;                                        // cannot happen: a group is defined by this bound
+    if (c >= n_groups) return;
+    const uint32_t a = groups.first[c], m_all = groups.count[c];
+    if (m_all == 0u || m_all > GROUP) return;                         // cannot happen: a group is defined by this bound
     for (uint32_t j = lane; j < m_all; j += 64) {
-        const float4 l = ilo[a + j], h = ihi[a + j];
+        const float4 l = plo[a + j], h = phi[a + j];
         blo[0][j] = l.x; blo[1][j] = l.y; blo[2][j] = l.z; bhi[0][j] = h.x; bhi[1][j] = h.y; bhi[2][j] = h.z;
         perm[j] = (uint16_t)j;
-        // a subtree over s shapes costs about its depth to pass through
-        if (!SHAPES) weight[j] = (uint8_t)(32 - __clz((int)(item_last[a + j] - item_first[a + j] + 1u)));
     }
     if (lane == 0) { task_start[0] = 0; task_count[0] = (uint16_t)m_all; task_depth[0] = (uint16_t)min(groups.depth[c], 60000u); task_link[0] = groups.link[c]; }
     __syncthreads();
-    uint32_t n_tasks = 1, next_slot = slot_base + a, leaves = 0, max_leaf = 0, max_depth = 0;
+    uint32_t n_tasks = 1, next_slot = a, leaves = 0, max_leaf = 0, max_depth = 0;
     double cost = 0.0;
     while (n_tasks > 0 && n_tasks + 2 <= (uint32_t)STACK) {
         n_tasks--;
@@ -383,82 +531,43 @@ __global__ __launch_bounds__(64) void build_groups(ItemList groups, ItemIndex in
                 lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
                 clo[k] = fminf(clo[k], __shfl_xor(clo[k], off, 64)); chi[k] = fmaxf(chi[k], __shfl_xor(chi[k], off, 64));
             }
-        const float area = (hi[0] - lo[0]) * (hi[1] - lo[1]) + (hi[1] - lo[1]) * (hi[2] - lo[2]) + (hi[2] - lo[2]) * (hi[0] - lo[0]);
-        // Depth budget: halving down to leaves takes `need` more levels here and `reserve` in the levels below.
-        const uint32_t leaf_items = SHAPES ? rtl::MAX_LEAF : 1u;
-        uint32_t need = 0;
-        while ((leaf_items << need) < m) need++;
-        const bool force_median = depth + need + 1u + reserve >= depth_limit;
-        bool make_leaf = m == 1u || (SHAPES && force_median && m <= rtl::MAX_LEAF);
-        int axis = -1; float threshold = 0.0f, scale = 0.0f, origin = 0.0f;     // items with bin(axis) <= threshold go left
-        if (!make_leaf && !force_median) {
+        const float area = half_area3(lo, hi);
+        const bool halve = must_halve(depth, m, depth_limit);
+        bool make_leaf = m == 1u || (halve && m <= rtl::MAX_LEAF);
+        int axis = -1; uint32_t split_bin = 0; float scale = 0.0f, origin = 0.0f;
+        if (!make_leaf && !halve) {
             for (uint32_t j = lane; j < 3u * BINS; j += 64) {
                 const uint32_t ax = j / BINS, b = j % BINS;
-                for (int k = 0; k < 3; k++) { bin_lo[ax][b][k] = 0xFFFFFFFFu; bin_hi[ax][b][k] = 0u; }
-                bin_cnt[ax][b] = 0u;
+                for (int k = 0; k < 3; k++) { bins.lo[ax][b][k] = 0xFFFFFFFFu; bins.hi[ax][b][k] = 0u; }
+                bins.cnt[ax][b] = 0u;
             }
             __syncthreads();
             float inv[3];
-            for (int k = 0; k < 3; k++) {
-                inv[k] = chi[k] > clo[k] ? (float)BINS * 0.999999f / (chi[k] - clo[k]) : 0.0f;
-                if (!(inv[k] < INFINITY)) inv[k] = 0.0f;
-            }
+            bin_scales(clo, chi, inv);
             for (uint32_t j = lane; j < m; j += 64) {
                 const uint32_t s = perm[start + j];
                 for (int ax = 0; ax < 3; ax++) {
                     if (inv[ax] == 0.0f) continue;
-                    int b = (int)((0.5f * blo[ax][s] + 0.5f * bhi[ax][s] - clo[ax]) * inv[ax]);
-                    b = min(max(b, 0), BINS - 1);
-                    for (int k = 0; k < 3; k++) { atomicMin(&bin_lo[ax][b][k], ordered(blo[k][s])); atomicMax(&bin_hi[ax][b][k], ordered(bhi[k][s])); }
-                    atomicAdd(&bin_cnt[ax][b], SHAPES ? 1u : (uint32_t)weight[s]);
+                    const int b = bin_of(blo[ax][s], bhi[ax][s], clo[ax], inv[ax]);
+                    for (int k = 0; k < 3; k++) { atomicMin(&bins.lo[ax][b][k], ordered(blo[k][s])); atomicMax(&bins.hi[ax][b][k], ordered(bhi[k][s])); }
+                    atomicAdd(&bins.cnt[ax][b], 1u);
                 }
             }
             __syncthreads();
-            // Candidate split after bin b of axis ax, spread over the lanes.
-            float best = INFINITY; int best_id = -1;
-            for (uint32_t cand = lane; cand < 3u * BINS; cand += 64) {
-                const uint32_t ax = cand / BINS, b = cand % BINS;
-                if (b + 1 < BINS && inv[ax] != 0.0f) {
-                    float l0[3] = {INFINITY, INFINITY, INFINITY}, h0[3] = {-INFINITY, -INFINITY, -INFINITY}, l1[3] = {INFINITY, INFINITY, INFINITY}, h1[3] = {-INFINITY, -INFINITY, -INFINITY};
-                    uint32_t n0 = 0, n1 = 0;
-                    for (uint32_t q = 0; q < (uint32_t)BINS; q++) {
-                        if (bin_cnt[ax][q] == 0u) continue;
-                        for (int k = 0; k < 3; k++) {
-                            const float l = unordered(bin_lo[ax][q][k]), h = unordered(bin_hi[ax][q][k]);
-                            if (q <= b) { l0[k] = fminf(l0[k], l); h0[k] = fmaxf(h0[k], h); } else { l1[k] = fminf(l1[k], l); h1[k] = fmaxf(h1[k], h); }
-                        }
-                        if (q <= b) n0 += bin_cnt[ax][q]; else n1 += bin_cnt[ax][q];
-                    }
-                    if (n0 && n1) {
-                        const float a0 = (h0[0] - l0[0]) * (h0[1] - l0[1]) + (h0[1] - l0[1]) * (h0[2] - l0[2]) + (h0[2] - l0[2]) * (h0[0] - l0[0]);
-                        const float a1 = (h1[0] - l1[0]) * (h1[1] - l1[1]) + (h1[1] - l1[1]) * (h1[2] - l1[2]) + (h1[2] - l1[2]) * (h1[0] - l1[0]);
-                        const float v = a0 * (float)n0 + a1 * (float)n1;
-                        if (v < best) { best = v; best_id = (int)cand; }       // overflow or NaN: not a candidate
-                    }
-                }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(best_id, off, 64);
-                if (oi >= 0 && (best_id < 0 || ob < best || (ob == best && oi < best_id))) { best = ob; best_id = oi; }
-            }
-            best = __shfl(best, 0, 64); best_id = __shfl(best_id, 0, 64);  // one decision for the whole wavefront
+            float best;
+            const int best_id = best_split(bins, inv, lane, &best);
             if (best_id >= 0) {
                 const float split_cost = COST_BOX + COST_SHAPE * (area > 0.0f ? best / area : (float)m);
-                if (SHAPES && m <= rtl::MAX_LEAF && COST_SHAPE * (float)m <= split_cost) make_leaf = true;
-                else { axis = best_id / BINS; threshold = (float)(best_id % BINS); scale = inv[axis]; origin = clo[axis]; }
-            } else if (SHAPES && m <= rtl::MAX_LEAF) {
+                if (m <= rtl::MAX_LEAF && COST_SHAPE * (float)m <= split_cost) make_leaf = true;
+                else { axis = best_id / BINS; split_bin = (uint32_t)(best_id % BINS); scale = inv[axis]; origin = clo[axis]; }
+            } else if (m <= rtl::MAX_LEAF) {
                 make_leaf = true;                                     // all centres coincide and the shapes fit one leaf
             }
         }
         if (make_leaf) {
-            if (lane == 0) {
-                if (SHAPES) hook(tmp, stats, link, rtl::REF_LEAF | ((a + start) << 3) | (m - 1u));
-                else { item_link[a + perm[start]] = link; item_depth[a + perm[start]] = depth; }
-            }
-            if (SHAPES) {
-                leaves++; max_leaf = max(max_leaf, m); max_depth = max(max_depth, depth);
-                cost += (double)COST_SHAPE * (double)m * (double)area;
-            }
+            if (lane == 0) hook(tmp, stats, link, rtl::REF_LEAF | ((a + start) << 3) | (m - 1u));
+            leaves++; max_leaf = max(max_leaf, m); max_depth = max(max_depth, depth);
+            cost += (double)COST_SHAPE * (double)m * (double)area;
             continue;
         }
         // Partition perm[start, start + m): by bin on the chosen axis, or in halves by position.
@@ -467,24 +576,14 @@ __global__ __launch_bounds__(64) void build_groups(ItemList groups, ItemIndex in
             for (uint32_t base = 0; base < m; base += 64) {
                 const uint32_t j = base + lane;
                 bool left = false;
-                if (j < m) {
-                    const uint32_t s = perm[start + j];
-                    int b = (int)((0.5f * blo[axis][s] + 0.5f * bhi[axis][s] - origin) * scale);
-                    b = min(max(b, 0), BINS - 1);
-                    left = (float)b <= threshold;
-                }
+                if (j < m) { const uint32_t s = perm[start + j]; left = (uint32_t)bin_of(blo[axis][s], bhi[axis][s], origin, scale) <= split_bin; }
                 nl += (uint32_t)__popcll(__ballot(left));
             }
             uint32_t at_left = 0, at_right = nl;
             for (uint32_t base = 0; base < m; base += 64) {
                 const uint32_t j = base + lane;
                 bool left = false, right = false; uint32_t s = 0;
-                if (j < m) {
-                    s = perm[start + j];
-                    int b = (int)((0.5f * blo[axis][s] + 0.5f * bhi[axis][s] - origin) * scale);
-                    b = min(max(b, 0), BINS - 1);
-                    left = (float)b <= threshold; right = !left;
-                }
+                if (j < m) { s = perm[start + j]; left = (uint32_t)bin_of(blo[axis][s], bhi[axis][s], origin, scale) <= split_bin; right = !left; }
                 const unsigned long long ml = __ballot(left), mr = __ballot(right), below = (1ull << lane) - 1ull;
                 if (left) scratch[at_left + (uint32_t)__popcll(ml & below)] = (uint16_t)s;
                 if (right) scratch[at_right + (uint32_t)__popcll(mr & below)] = (uint16_t)s;
@@ -529,42 +628,11 @@ __global__ __launch_bounds__(64) void build_groups(ItemList groups, ItemIndex in
         __syncthreads();
     }
     if (n_tasks > 0 && lane == 0) atomicMax(&stats->max_depth, 0x7FFFFFFFu);   // stack bound broken (cannot happen): reported as a tree that is too deep
-    if (SHAPES)                                                       // the order of the shapes inside the group's range follows the leaves
-        for (uint32_t j = lane; j < m_all; j += 64) tmp.order_out[a + j] = order_in[a + perm[j]];
+    for (uint32_t j = lane; j < m_all; j += 64) tmp.order_out[a + j] = order_in[a + perm[j]];
     if (lane == 0) {
-        if (SHAPES) { atomicAdd(&stats->n_leaves, leaves); atomicMax(&stats->max_leaf, max_leaf); atomicMax(&stats->max_depth, max_depth); }
+        atomicAdd(&stats->n_leaves, leaves); atomicMax(&stats->max_leaf, max_leaf); atomicMax(&stats->max_depth, max_depth);
         if (root_area > 0.0f) atomicAdd(&stats->cost_micro, (unsigned long long)(cost / (double)root_area * 1e6));
     }
-}
-
-// Radix nodes above the last level (more than GROUP of its items) become node pairs as they are, in the temporary
-// slots slot_base + i, and hand link and depth to the groups below them.
-__global__ __launch_bounds__(256) void emit_upper(uint32_t n, Topology t, NodeData d, const float4* __restrict__ slo, const float4* __restrict__ shi,
-                                                  ItemIndex items, ItemIndex groups, ItemList top, uint32_t slot_base, Grid g, TempTree tmp,
-                                                  float root_area, BuildStats* __restrict__ stats) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1 || items.under(t, i) <= GROUP) return;
-    rtl::QuantPair out;
-    const uint32_t c[2] = {t.left[i], t.right[i]};
-    uint32_t depth = 1;                                            // pairs from the root down to and including this one
-    for (uint32_t up = t.parent[i]; up != NONE && depth < 1024u; up = t.parent[up]) depth++;
-    for (int k = 0; k < 2; k++) {
-        float4 lo, hi; uint32_t ref = rtl::REF_EMPTY, below;       // a group's reference is hooked in when the group is built
-        if (c[k] & LEAF_BIT) { const uint32_t p = c[k] & ~LEAF_BIT; lo = slo[p]; hi = shi[p]; below = p; }
-        else {
-            below = t.first[c[k]];
-            if (items.under(t, c[k]) > GROUP) { ref = slot_base + c[k]; lo = d.lo[c[k]]; hi = d.hi[c[k]]; }
-            else { const uint32_t j = groups.of(below); lo = top.lo[j]; hi = top.hi[j]; }
-        }
-        if (ref == rtl::REF_EMPTY) { const uint32_t j = groups.of(below); top.link[j] = (slot_base + i) * 2u + (uint32_t)k; top.depth[j] = depth; }
-        const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
-        quantise_box(g, l, h, &out.c[k]);
-        out.c[k].ref = ref;
-    }
-    tmp.pairs[slot_base + i] = out;
-    tmp.used[slot_base + i] = 1u;
-    if (i == 0) stats->root_ref = slot_base;
-    if (root_area > 0.0f) atomicAdd(&stats->cost_micro, (unsigned long long)((double)COST_BOX * half_area(d.lo[i], d.hi[i]) / (double)root_area * 1e6));
 }
 
 // Temporary slots -> consecutive node pairs of the blob, references renumbered.
@@ -611,7 +679,7 @@ struct DeviceBuffers {               // everything the build needs besides the b
 BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltScene* out, std::string* err) {
     const uint32_t n = in.n_tree;
     if (n < 2 || n > rtl::MAX_TREE_SHAPES) { *err = "GPU tree build needs between 2 and 2^27 shapes"; return BUILD_FAILED; }
-    const uint32_t blocks_n = (n + 255) / 256, blocks_i = (n - 1 + 255) / 256;
+    const uint32_t blocks_n = (n + 255) / 256;
     DeviceBuffers mem;
     rtl::ShapeRec* d_rec; float4 *d_lo, *d_hi, *d_slo, *d_shi; Bounds* d_bounds;
     uint64_t *d_keys, *d_keys_sorted; uint32_t *d_vals, *d_order;
@@ -626,7 +694,7 @@ BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltSc
     GPU_TRY(hipMemcpyAsync(d_bounds, &init, sizeof(init), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(shape_boxes, dim3(std::min(blocks_n, BOXES_BLOCKS)), dim3(256), 0, stream, d_rec, n, d_lo, d_hi, d_bounds);
     GPU_TRY(hipGetLastError());
-    // 2. Morton codes, sort
+    // 2. Morton codes, sort; from here on a shape is known by its place in the sorted order
     hipLaunchKernelGGL(morton_codes, dim3(blocks_n), dim3(256), 0, stream, d_lo, d_hi, n, d_bounds, d_keys, d_vals);
     GPU_TRY(hipGetLastError());
     size_t sort_bytes = 0;
@@ -639,13 +707,6 @@ BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltSc
     GPU_TRY(hipMemcpyAsync(&bounds, d_bounds, sizeof(bounds), hipMemcpyDeviceToHost, stream));
     GPU_TRY(hipStreamSynchronize(stream));
     if (bounds.v[12]) { *err = "rt_scene: non-finite shape coordinates"; return BUILD_FAILED; }
-
-    // 3. radix tree
-    Topology t;
-    GPU_TRY(mem.alloc(&t.left, n)); GPU_TRY(mem.alloc(&t.right, n)); GPU_TRY(mem.alloc(&t.parent, n)); GPU_TRY(mem.alloc(&t.leaf_parent, n)); GPU_TRY(mem.alloc(&t.first, n));
-    GPU_TRY(mem.alloc(&t.last, n));
-    hipLaunchKernelGGL(radix_tree, dim3(blocks_i), dim3(256), 0, stream, d_keys_sorted, n, t);
-    GPU_TRY(hipGetLastError());
 
     // Grid over the padded box of all tree shapes, as the host builder lays it out.
     rtl::BlobHeader h{};
@@ -664,98 +725,95 @@ BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltSc
     float root_area = ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0];
     if (!std::isfinite(root_area)) root_area = 0.0f;
 
-    // 4. groups, level by level from the shapes up: lists[k] holds the groups of level k + 1 = the items of level k + 2
-    uint32_t* d_start; GPU_TRY(mem.alloc(&d_start, n));
-    ItemIndex index[LEVELS + 1]; index[0].incl = nullptr;
-    ItemList lists[LEVELS];
-    int levels = 0;
-    uint32_t items_in = n;                  // items of the level being grouped
-    const int max_levels = in.group_levels >= 1 && in.group_levels <= (uint32_t)LEVELS ? (int)in.group_levels : LEVELS;
-    while (levels < max_levels) {
-        uint32_t* d_incl; GPU_TRY(mem.alloc(&d_incl, n));
-        GPU_TRY(hipMemsetAsync(d_start, 0, (size_t)n * sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(mark_groups, dim3(blocks_n), dim3(256), 0, stream, n, t, index[levels], d_start);
-        GPU_TRY(hipGetLastError());
-        size_t need_bytes = 0;
-        GPU_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, need_bytes, d_start, d_incl, (int)n, stream));
-        uint8_t* d_scan_temp; GPU_TRY(mem.alloc(&d_scan_temp, need_bytes));
-        GPU_TRY(hipcub::DeviceScan::InclusiveSum(d_scan_temp, need_bytes, d_start, d_incl, (int)n, stream));
-        uint32_t count = 0;
-        GPU_TRY(hipMemcpyAsync(&count, d_incl + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-        GPU_TRY(hipStreamSynchronize(stream));
-        if (count == 0 || count > items_in) { *err = "internal: the GPU tree build lost its groups"; return BUILD_FAILED; }
-        index[levels + 1].incl = d_incl;
-        ItemList& l = lists[levels];
-        l.count = count;
-        GPU_TRY(mem.alloc(&l.first, count)); GPU_TRY(mem.alloc(&l.last, count)); GPU_TRY(mem.alloc(&l.lo, count)); GPU_TRY(mem.alloc(&l.hi, count));
-        GPU_TRY(mem.alloc(&l.link, count)); GPU_TRY(mem.alloc(&l.depth, count));
-        hipLaunchKernelGGL(list_groups, dim3(blocks_n), dim3(256), 0, stream, n, t, index[levels], index[levels + 1], l);
-        GPU_TRY(hipGetLastError());
-        hipLaunchKernelGGL(group_boxes, dim3((count + 3) / 4), dim3(256), 0, stream, l, index[levels], levels == 0 ? (const float4*)d_slo : (const float4*)lists[levels - 1].lo,
-                           levels == 0 ? (const float4*)d_shi : (const float4*)lists[levels - 1].hi);
-        GPU_TRY(hipGetLastError());
-        levels++;
-        items_in = count;
-        if (count == 1) break;              // the root of the radix tree is a group: nothing is left above
-    }
-
-    // 5. temporary slots: one range per level (as many slots as the level has items), one for the radix nodes left above
-    uint32_t slot_base[LEVELS + 1];
-    uint64_t slots64 = 0;
-    for (int k = 0; k < levels; k++) { slot_base[k] = (uint32_t)slots64; slots64 += k == 0 ? n : lists[k - 1].count; }
-    const bool upper = lists[levels - 1].count > 1;
-    slot_base[levels] = (uint32_t)slots64;
-    if (upper) slots64 += n - 1;
-    if (slots64 >= (1ull << 30)) { *err = "GPU tree build: too many temporary node pairs"; return BUILD_FAILED; }
-    const uint32_t slots = (uint32_t)slots64;
+    // Temporary slots: [0, n) for the groups, [n, 2n) for the large nodes (there are far fewer, but how many is not known beforehand).
+    const uint32_t slots = 2u * n;
     TempTree tmp;
     uint32_t* d_new_index;
     GPU_TRY(mem.alloc(&tmp.pairs, slots)); GPU_TRY(mem.alloc(&tmp.used, slots)); GPU_TRY(mem.alloc(&d_new_index, slots)); GPU_TRY(mem.alloc(&tmp.order_out, n));
     GPU_TRY(hipMemsetAsync(tmp.used, 0, (size_t)slots * sizeof(uint32_t), stream));
     BuildStats* d_stats; GPU_TRY(mem.alloc(&d_stats, 1));
     GPU_TRY(hipMemsetAsync(d_stats, 0, sizeof(BuildStats), stream));
-    NodeData d{};
-    if (upper) {
-        // boxes of the radix nodes that stay, bottom-up; the count of unfinished nodes comes back every few rounds
-        GPU_TRY(mem.alloc(&d.lo, n)); GPU_TRY(mem.alloc(&d.hi, n)); GPU_TRY(mem.alloc(&d.done, n));
-        uint32_t* d_remaining; GPU_TRY(mem.alloc(&d_remaining, 1));
-        uint32_t remaining = 0;
-        GPU_TRY(hipMemsetAsync(d.done, 0, (size_t)n * sizeof(uint32_t), stream));
-        GPU_TRY(hipMemsetAsync(d_remaining, 0, sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(count_upper, dim3(blocks_i), dim3(256), 0, stream, n, t, index[levels - 1], d_remaining);
-        GPU_TRY(hipGetLastError());
-        GPU_TRY(hipMemcpyAsync(&remaining, d_remaining, sizeof(remaining), hipMemcpyDeviceToHost, stream));
-        GPU_TRY(hipStreamSynchronize(stream));
-        const uint32_t MAX_ROUNDS = 160;      // height of the radix tree is at most 63 + 28 key and position bits
-        uint32_t round = 1;
-        while (remaining != 0 && round <= MAX_ROUNDS) {
-            for (int k = 0; k < 8; k++, round++) {
-                hipLaunchKernelGGL(fit_upper_round, dim3(blocks_i), dim3(256), 0, stream, n, round, t, d, d_slo, d_shi, index[levels - 1], index[levels], lists[levels - 1], d_remaining);
-                GPU_TRY(hipGetLastError());
-            }
-            GPU_TRY(hipMemcpyAsync(&remaining, d_remaining, sizeof(remaining), hipMemcpyDeviceToHost, stream));
-            GPU_TRY(hipStreamSynchronize(stream));
-        }
-        if (remaining != 0) { *err = "internal: the bottom-up pass of the GPU tree build did not finish"; return BUILD_FAILED; }
-        hipLaunchKernelGGL(emit_upper, dim3(blocks_i), dim3(256), 0, stream, n, t, d, d_slo, d_shi, index[levels - 1], index[levels], lists[levels - 1],
-                           slot_base[levels], g, tmp, root_area, d_stats);
-        GPU_TRY(hipGetLastError());
-    }
-    // from the top level down; each level needs at most 8 node pairs of depth below it (5 for the shapes: leaves of 8)
-    for (int k = levels - 1; k >= 1; k--) {
-        hipLaunchKernelGGL(build_groups<false>, dim3(lists[k].count), dim3(64), 0, stream, lists[k], index[k], (const float4*)lists[k - 1].lo, (const float4*)lists[k - 1].hi,
-                           (const uint32_t*)lists[k - 1].first, (const uint32_t*)lists[k - 1].last, lists[k - 1].link, lists[k - 1].depth, slot_base[k],
-                           (const uint32_t*)nullptr, g, tmp, in.depth_limit, (uint32_t)(5 + 8 * (k - 1)), root_area, d_stats);
-        GPU_TRY(hipGetLastError());
-    }
-    hipLaunchKernelGGL(build_groups<true>, dim3(lists[0].count), dim3(64), 0, stream, lists[0], index[0], (const float4*)d_slo, (const float4*)d_shi,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, slot_base[0],
-                       (const uint32_t*)d_order, g, tmp, in.depth_limit, 0u, root_area, d_stats);
+
+    // 3. large nodes, a level per round
+    const uint32_t max_nodes = n / (GROUP + 1u) + 1u;                  // nodes of a level are disjoint and hold more than GROUP shapes each
+    const uint32_t max_chunks = n / CHUNK + max_nodes + 1u;
+    BigNode *d_nodes_a, *d_nodes_b; uint32_t *d_idx, *d_idx_out, *d_n_chunks_of, *d_chunk_off, *d_next_index;
+    Level lv{};
+    GroupList groups;
+    GPU_TRY(mem.alloc(&d_nodes_a, max_nodes + 2)); GPU_TRY(mem.alloc(&d_nodes_b, max_nodes + 2)); GPU_TRY(mem.alloc(&d_idx, n)); GPU_TRY(mem.alloc(&d_idx_out, n));
+    GPU_TRY(mem.alloc(&d_n_chunks_of, max_nodes + 2)); GPU_TRY(mem.alloc(&d_chunk_off, max_nodes + 2)); GPU_TRY(mem.alloc(&d_next_index, max_nodes + 2));
+    GPU_TRY(mem.alloc(&lv.bins, max_nodes)); GPU_TRY(mem.alloc(&lv.chunk_cnt, (size_t)max_chunks * 3u * BINS)); GPU_TRY(mem.alloc(&lv.chunk_left, max_chunks));
+    GPU_TRY(mem.alloc(&lv.split, max_nodes)); GPU_TRY(mem.alloc(&lv.sides, 2 * (size_t)max_nodes)); GPU_TRY(mem.alloc(&lv.n_big, max_nodes + 2));
+    GPU_TRY(mem.alloc(&groups.first, n)); GPU_TRY(mem.alloc(&groups.count, n)); GPU_TRY(mem.alloc(&groups.link, n)); GPU_TRY(mem.alloc(&groups.depth, n));
+    size_t scan_bytes = 0;
+    GPU_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_n_chunks_of, d_chunk_off, (int)(max_nodes + 1), stream));
+    uint8_t* d_scan_temp; GPU_TRY(mem.alloc(&d_scan_temp, scan_bytes));
+    // the permutation starts as the sorted order
+    hipLaunchKernelGGL(iota, dim3(blocks_n), dim3(256), 0, stream, d_idx, d_idx_out, n);
     GPU_TRY(hipGetLastError());
+    uint32_t n_nodes = 0, nodes_before = 0;
+    if (n > GROUP) {
+        BigNode root{};
+        root.first = 0; root.count = n; root.link = NONE; root.depth = 0;
+        for (int k = 0; k < 3; k++) { root.clo[k] = bounds.v[6 + k]; root.chi[k] = bounds.v[9 + k]; }
+        GPU_TRY(hipMemcpyAsync(d_nodes_a, &root, sizeof(root), hipMemcpyHostToDevice, stream));
+        GPU_TRY(hipStreamSynchronize(stream));                         // the source is on this function's stack
+        n_nodes = 1;
+    } else {
+        const uint32_t one[4] = {0u, n, NONE, 0u};                      // the whole scene is one group
+        GPU_TRY(hipMemcpyAsync(groups.first, &one[0], 4, hipMemcpyHostToDevice, stream)); GPU_TRY(hipMemcpyAsync(groups.count, &one[1], 4, hipMemcpyHostToDevice, stream));
+        GPU_TRY(hipMemcpyAsync(groups.link, &one[2], 4, hipMemcpyHostToDevice, stream)); GPU_TRY(hipMemcpyAsync(groups.depth, &one[3], 4, hipMemcpyHostToDevice, stream));
+        const uint32_t one_group = 1u;
+        GPU_TRY(hipMemcpyAsync(&d_stats->n_groups, &one_group, 4, hipMemcpyHostToDevice, stream));
+        GPU_TRY(hipStreamSynchronize(stream));                         // the sources are on this function's stack
+    }
+    BigNode *cur = d_nodes_a, *next = d_nodes_b;
+    for (uint32_t round = 0; n_nodes > 0; round++) {
+        if (round > in.depth_limit || nodes_before + n_nodes > n) return BUILD_TOO_DEEP;
+        lv.nodes = cur; lv.n_nodes = n_nodes; lv.chunk_off = d_chunk_off;
+        const uint32_t chunk_blocks = std::min<uint64_t>(max_chunks, (uint64_t)n / CHUNK + n_nodes);   // at most one partly filled chunk per node
+        const uint32_t init_threads = std::max(n_nodes * 3u * BINS, n_nodes + 1u);
+        hipLaunchKernelGGL(level_begin, dim3((init_threads + 255) / 256), dim3(256), 0, stream, lv, d_n_chunks_of);
+        GPU_TRY(hipGetLastError());
+        GPU_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_temp, scan_bytes, d_n_chunks_of, d_chunk_off, (int)(n_nodes + 1), stream));
+        hipLaunchKernelGGL(bin_chunks, dim3(chunk_blocks), dim3(256), 0, stream, lv, d_idx, d_slo, d_shi, in.depth_limit);
+        GPU_TRY(hipGetLastError());
+        hipLaunchKernelGGL(split_nodes, dim3((n_nodes + 3) / 4), dim3(256), 0, stream, lv, in.depth_limit);
+        GPU_TRY(hipGetLastError());
+        GPU_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_temp, scan_bytes, lv.n_big, d_next_index, (int)(n_nodes + 1), stream));
+        hipLaunchKernelGGL(move_chunks, dim3(chunk_blocks), dim3(256), 0, stream, lv, d_idx, d_idx_out, d_slo, d_shi);
+        GPU_TRY(hipGetLastError());
+        hipLaunchKernelGGL(copy_chunks, dim3(chunk_blocks), dim3(256), 0, stream, lv, d_idx_out, d_idx);
+        GPU_TRY(hipGetLastError());
+        hipLaunchKernelGGL(emit_nodes, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, lv, d_next_index, next, groups, n + nodes_before, g, tmp, root_area, d_stats);
+        GPU_TRY(hipGetLastError());
+        uint32_t n_next = 0;
+        GPU_TRY(hipMemcpyAsync(&n_next, d_next_index + n_nodes, 4, hipMemcpyDeviceToHost, stream));
+        GPU_TRY(hipStreamSynchronize(stream));
+        if (n_next > max_nodes) { *err = "internal: the GPU tree build made more large nodes than fit a level"; return BUILD_FAILED; }
+        nodes_before += n_nodes;
+        n_nodes = n_next;
+        std::swap(cur, next);
+    }
+    uint32_t n_groups = 0;
+    GPU_TRY(hipMemcpyAsync(&n_groups, &d_stats->n_groups, 4, hipMemcpyDeviceToHost, stream));
+    GPU_TRY(hipStreamSynchronize(stream));
+    if (n_groups == 0 || n_groups > n) { *err = "internal: the GPU tree build lost its groups"; return BUILD_FAILED; }
+
+    // 4. small nodes
+    uint32_t* d_order_p;
+    GPU_TRY(mem.alloc(&d_order_p, n));
+    hipLaunchKernelGGL(gather_by_index, dim3(blocks_n), dim3(256), 0, stream, d_idx, n, d_slo, d_shi, d_order, d_lo, d_hi, d_order_p);     // d_lo / d_hi are free again
+    GPU_TRY(hipGetLastError());
+    hipLaunchKernelGGL(build_groups, dim3(n_groups), dim3(64), 0, stream, groups, n_groups, (const float4*)d_lo, (const float4*)d_hi, (const uint32_t*)d_order_p, g, tmp,
+                       in.depth_limit, root_area, d_stats);
+    GPU_TRY(hipGetLastError());
+
+    // 5. numbering of the slots in use
     size_t need_bytes = 0;
     GPU_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need_bytes, tmp.used, d_new_index, (int)slots, stream));
-    uint8_t* d_scan_temp; GPU_TRY(mem.alloc(&d_scan_temp, need_bytes));
-    GPU_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_temp, need_bytes, tmp.used, d_new_index, (int)slots, stream));
+    uint8_t* d_scan_temp2; GPU_TRY(mem.alloc(&d_scan_temp2, need_bytes));
+    GPU_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_temp2, need_bytes, tmp.used, d_new_index, (int)slots, stream));
     uint32_t last_index = 0, last_used = 0;
     BuildStats stats;
     GPU_TRY(hipMemcpyAsync(&last_index, d_new_index + (slots - 1), 4, hipMemcpyDeviceToHost, stream));
@@ -771,7 +829,7 @@ BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltSc
         GPU_TRY(hipStreamSynchronize(stream));
     } else if (n_pairs != 0) { *err = "internal: a single-leaf GPU tree with node pairs"; return BUILD_FAILED; }
 
-    // 7. the blob
+    // 6. the blob
     h.magic = rtl::BLOB_MAGIC; h.version = rtl::BLOB_VERSION;
     h.n_pairs = n_pairs; h.n_tree_shapes = n; h.n_list_shapes = in.n_list; h.n_materials = in.n_mats; h.n_lights = in.n_lights;
     h.root_ref = root_ref;

@@ -278,7 +278,6 @@ int rt_upload_scene_ex(const rt_scene* scene, uint32_t flags) {
     in.mats = parts.mats.data(); in.n_mats = (uint32_t)parts.mats.size();
     in.lights = parts.lights.data(); in.n_lights = (uint32_t)parts.lights.size();
     in.finite_shading = parts.finite_shading; in.pad_abs = parts.pad_abs; in.depth_limit = rtp::TREE_DEPTH_LIMIT;
-    in.group_levels = (flags >> 8) & 7u;
     HIP_TRY(hipSetDevice(g.device));
     if (sync_lanes()) return 1;
     rtg::BuiltScene built{};

@@ -372,21 +372,6 @@ def test_gpu_built_tree_renders_the_reference_frames():
     assert np.array_equal(tracer.render().pixels(), host)
 
 
-@pytest.mark.parametrize("levels", [1, 2, 3])
-def test_gpu_built_tree_with_the_radix_tree_kept_above_some_levels_of_groups(levels):
-    """100 000 triangles: one level of groups leaves some 600 groups under radix nodes, two levels a handful,
-    three none; the frame is the same every time and the blob is a proper tree."""
-    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
-    host = rt.RayTracer(cfg).render().pixels()
-    info = rt.upload_scene(cfg.scene(), gpu_build=True, group_levels=levels)
-    _assert_gpu_built_scene_is_sound(info)
-    full = rt.upload_scene(cfg.scene(), gpu_build=True)
-    assert (info["node_pairs"], info["sah_cost"]) != (full["node_pairs"], full["sah_cost"]) or levels == 3
-    rt.upload_scene(cfg.scene(), gpu_build=True, group_levels=levels)
-    got, _ = rt.render(cfg.frame())
-    assert np.array_equal(got, host)
-
-
 @pytest.mark.parametrize("seed,ntri,nsph,npl,nlights,maxdepth", [(11, 300, 40, 1, 2, 4), (12, 2000, 0, 0, 1, 3), (13, 9, 0, 2, 1, 2), (14, 0, 150, 1, 3, 5)])
 def test_gpu_built_tree_against_exhaustive_oracle(seed, ntri, nsph, npl, nlights, maxdepth):
     text = _random_scene(np.random.default_rng(seed), ntri, nsph, npl, nlights, maxdepth)
@@ -406,13 +391,12 @@ def test_gpu_tree_build_on_degenerate_and_adversarial_input():
     mat = (0.5, 0.5, 0.5, 0.2, 0.2, 0.2, 10.0)
     tri = np.float32([[-1, -1, 0, 1, -1, 0, 0, 1, 0]])
     cases = {
-        "identical": np.repeat(tri, 500, axis=0),                                   # equal Morton codes: ties broken by position
+        "identical": np.repeat(tri, 500, axis=0),                                   # a large node that no split separates: halved by position
         "collinear centres": tri + np.float32([[1, 0, 0] * 3]) * np.arange(40, dtype=np.float32)[:, None] * 0.01,
         "points": np.repeat(np.float32([[0.5, 0.5, 0.5] * 3]), 20, axis=0),         # zero-extent boxes
     }
-    # one point per bit of the 63-bit Morton code (on the three axes, at powers of two) plus many copies of
-    # the smallest: a radix tree deeper than the traversal stack; the split search inside the groups of the
-    # radix tree has to bring the depth back under the limit
+    # points at powers of two on the three axes, over 21 octaves, plus many copies of the smallest: most of
+    # every node's shapes fall into its first bin, level after level
     pts = np.zeros((63, 3))
     for b in range(63):
         pts[b, b % 3] = 1e-5 * 2.0 ** (b // 3)
