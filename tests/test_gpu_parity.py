@@ -372,6 +372,17 @@ def test_gpu_built_tree_renders_the_reference_frames():
     assert np.array_equal(tracer.render().pixels(), host)
 
 
+def test_gpu_built_blob_is_the_same_every_time():
+    """Atomics only ever add integers or take minima and maxima, and node numbers come from prefix sums:
+    two builds of one scene give the same bytes (what a scene cache file is keyed on)."""
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
+    blobs = []
+    for _ in range(3):
+        rt.upload_scene(cfg.scene(), gpu_build=True)
+        blobs.append(rt.download_scene_blob().copy())
+    assert np.array_equal(blobs[0], blobs[1]) and np.array_equal(blobs[0], blobs[2])
+
+
 @pytest.mark.parametrize("seed,ntri,nsph,npl,nlights,maxdepth", [(11, 300, 40, 1, 2, 4), (12, 2000, 0, 0, 1, 3), (13, 9, 0, 2, 1, 2), (14, 0, 150, 1, 3, 5)])
 def test_gpu_built_tree_against_exhaustive_oracle(seed, ntri, nsph, npl, nlights, maxdepth):
     text = _random_scene(np.random.default_rng(seed), ntri, nsph, npl, nlights, maxdepth)
