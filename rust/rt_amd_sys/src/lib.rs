@@ -1,4 +1,5 @@
-//! Raw bindings to `include/rt_amd.h` (and the scene-cache part of `include/rt_host.h`) plus a thin safe layer.
+//! Raw bindings to `include/rt_amd.h` (all of it) and to the scene-cache and PNG part of `include/rt_host.h`
+//! (its parser and comparator twins are not bound: the Rust host has the originals), plus a thin safe layer.
 //!
 //! Not compiled where it was written (no Rust toolchain there); the declarations follow the C
 //! header field for field.  Every struct is `#[repr(C)]` plain data.
@@ -60,6 +61,19 @@ pub struct rt_stats {
     pub total_ms: f64,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct rt_bvh_info {
+    pub node_pairs: u32,
+    pub leaves: u32,
+    pub max_depth: u32,
+    pub max_leaf: u32,
+    pub bvh_prims: u32,
+    pub list_prims: u32,
+    pub build_ms: f64,
+    pub sah_cost: f64,
+}
+
 pub const RT_BUILD_ON_GPU: u32 = 1;
 
 /// Opaque handles of `include/rt_host.h`.
@@ -69,7 +83,11 @@ pub struct rth_config { _private: [u8; 0] }
 pub struct rth_scene_cache { _private: [u8; 0] }
 
 extern "C" {
+    /// The reference computes these constants itself (raytracer.rs:46-55); this is for callers that do not.
+    pub fn rt_frame_from_camera(position: *const f32, look_at: *const f32, up: *const f32, fov_degrees: f32, width: u32, height: u32,
+                                maxdepth: u32, ambient: *const f32, out: *mut rt_frame) -> c_int;
     pub fn rt_init(device: c_int) -> c_int;
+    pub fn rt_get_bvh_info(out: *mut rt_bvh_info) -> c_int;
     pub fn rt_upload_scene(scene: *const rt_scene) -> c_int;
     /// `flags`: `RT_BUILD_ON_GPU` builds the tree on the GPU (same split search, an order of magnitude faster for big scenes).
     pub fn rt_upload_scene_ex(scene: *const rt_scene, flags: u32) -> c_int;
