@@ -2,8 +2,8 @@
  *
  * The reference keeps scene parsing, the scene model and image comparison in Rust
  * (src/raytracer/config/config_builder.rs, src/imgcomparator/mod.rs).  A Rust host would keep
- * using its own; these twins exist so that hosts without the Rust crate (the C++ command line
- * tool, the Python tests and benchmark) load the same .scene files, flatten them into
+ * using its own; these twins exist so that hosts without the Rust crate (the Python package, its
+ * tests and the benchmark) load the same .scene files, flatten them into
  * rt_scene / rt_frame exactly as the Rust side would, and compare images the way the
  * reference's tests do.  Nothing here touches the GPU.
  */
