@@ -1,14 +1,31 @@
-// frame.cpp -- the per-frame constants of RayTracer::render, computed on the host (no GPU involved).
+// frame.cpp -- host-side helpers of the render calls that need no GPU: the per-frame constants of RayTracer::render
+// and the copy of a finished frame out of the pinned staging buffer.
 #include "../../include/rt_amd.h"
 
 #include <cmath>
+#include <cstring>
 #include <string>
 
 #include "errors.h"
+#include "host_copy.h"
 
 namespace {
 int fail_msg(const std::string& m) { rte::set_error(m); return 1; }
 }  // namespace
+
+namespace rtu {
+
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+    const size_t PIECE = (size_t)1 << 20;
+    const long long pieces = (long long)((bytes + PIECE - 1) / PIECE);
+#pragma omp parallel for schedule(static) if (pieces >= 4) num_threads(8)
+    for (long long p = 0; p < pieces; p++) {
+        const size_t a = (size_t)p * PIECE, n = bytes - a < PIECE ? bytes - a : PIECE;
+        std::memcpy((char*)dst + a, (const char*)src + a, n);
+    }
+}
+
+}  // namespace rtu
 
 extern "C" {
 

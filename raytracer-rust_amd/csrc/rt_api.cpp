@@ -7,6 +7,7 @@
 // every entry point that needs the GPU fails with an error when HIP does.
 #include "../../include/rt_amd.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -18,6 +19,7 @@
 #include "bvh_gpu.h"
 #include "device_types.h"
 #include "errors.h"
+#include "host_copy.h"
 #include "layout.h"
 #include "scene_pack.h"
 
@@ -49,6 +51,10 @@ struct State {
     DevScene dsc{};
     rt_bvh_info info{};
     uint32_t* d_out = nullptr; size_t out_cap = 0;          // pixels (rt_render's frame before it is copied to the host)
+    // rt_render's way to the caller's (pageable) memory: pinned staging buffer, filled piece by piece by the copy
+    // engine while the pieces that have arrived are copied on by the host's threads
+    uint32_t* h_stage = nullptr; size_t stage_cap = 0;
+    hipEvent_t piece_done[8] = {};
     uint64_t scene_generation = 0;                          // bumped whenever another scene becomes resident
 };
 State g;
@@ -359,10 +365,25 @@ int rt_render(const rt_frame* frame, uint32_t* out_pixels, rt_stats* stats, int 
         HIP_TRY(hipMalloc((void**)&g.d_out, npix * sizeof(uint32_t)));
         g.out_cap = npix;
     }
+    if (npix > g.stage_cap) {
+        if (g.h_stage) { (void)hipHostFree(g.h_stage); g.h_stage = nullptr; g.stage_cap = 0; }
+        HIP_TRY(hipHostMalloc((void**)&g.h_stage, npix * sizeof(uint32_t), hipHostMallocDefault));
+        g.stage_cap = npix;
+    }
     rt_stats local{};
     if (render_shard(frame, 0, 1, 8, g.d_out, &local, count_work)) return 1;
-    HIP_TRY(hipMemcpyAsync(out_pixels, g.d_out, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, cur().stream));
-    HIP_TRY(hipStreamSynchronize(cur().stream));
+    const size_t n_pieces = npix >= (1u << 20) ? 8 : 1, per_piece = (npix + n_pieces - 1) / n_pieces;
+    for (size_t k = 0; k < n_pieces; k++) {
+        const size_t a = std::min(npix, k * per_piece), b = std::min(npix, a + per_piece);
+        if (!g.piece_done[k]) HIP_TRY(hipEventCreateWithFlags(&g.piece_done[k], hipEventDisableTiming));
+        if (b > a) HIP_TRY(hipMemcpyAsync(g.h_stage + a, g.d_out + a, (b - a) * sizeof(uint32_t), hipMemcpyDeviceToHost, cur().stream));
+        HIP_TRY(hipEventRecord(g.piece_done[k], cur().stream));
+    }
+    for (size_t k = 0; k < n_pieces; k++) {
+        const size_t a = std::min(npix, k * per_piece), b = std::min(npix, a + per_piece);
+        HIP_TRY(hipEventSynchronize(g.piece_done[k]));
+        rtu::parallel_copy(out_pixels + a, g.h_stage + a, (b - a) * sizeof(uint32_t));
+    }
     if (stats) {
         *stats = local;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -428,6 +449,8 @@ void rt_shutdown(void) {
     (void)sync_lanes();
     release_scene();
     if (g.d_out) (void)hipFree(g.d_out);
+    if (g.h_stage) (void)hipHostFree(g.h_stage);
+    for (hipEvent_t e : g.piece_done) if (e) (void)hipEventDestroy(e);
     for (Lane& l : g.lanes) {
         if (l.d_fold) (void)hipFree(l.d_fold);
         if (l.d_counters) (void)hipFree(l.d_counters);
