@@ -9,7 +9,8 @@ One step = one frame.  With N ranks the frame is cut into interleaved 8-row tile
 rank t % N), every rank renders its tiles with the scene replicated by one RCCL broadcast
 (outside the timed region, like the reference's BVH build, src/main.rs:11-15), and each frame
 ends with one RCCL gather of the compact row buffers to rank 0, which restores frame order
-(frames are pipelined two deep: the gather of one frame overlaps the kernel of the next).
+(frames are pipelined two deep, four deep on more than four GPUs: the gather of one frame overlaps the
+kernels of the next).
 The total work is fixed as N grows: "scaling": "strong".
 
 Rank 0 prints ONE JSON line.  `value` counts primary + shadow rays per second (the wording of
@@ -78,7 +79,7 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=0, help="frames in flight per GPU (default: 1 on one GPU, 2 with several)")
+    ap.add_argument("--lanes", type=int, default=0, help="frames in flight per GPU (default: 1 on one GPU, 2 on up to four, 4 beyond)")
     args = ap.parse_args()
 
     # Libraries underneath (RCCL prints a version banner) write to file descriptor 1; the contract is
@@ -149,7 +150,7 @@ def main():
     primary, shadow, secondary, nodes, prims = (int(x) for x in counts.cpu().tolist())
 
     def sync_all():
-        torch.cuda.synchronize(renderer.device)        # every stream of the device, both lanes included
+        torch.cuda.synchronize(renderer.device)        # every stream of the device, all lanes included
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize(renderer.device)

@@ -490,8 +490,11 @@ def pack_rgb(pixels_ptr, width, height, rgb_ptr):
     _check(lib().rt_pack_rgb(C.c_void_p(pixels_ptr), width, height, C.c_void_p(rgb_ptr)))
 
 
+LANES = 4          # RT_LANES of rt_amd.h
+
+
 def select_lane(lane):
-    """Chooses which of the two lanes (stream + work buffers) the following calls use."""
+    """Chooses which of the LANES lanes (stream + work buffers each) the following calls use."""
     _check(lib().rt_select_lane(int(lane)))
 
 

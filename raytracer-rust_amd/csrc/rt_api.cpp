@@ -3,7 +3,7 @@
 // One process drives one GPU.  The scene lives in one device blob (layout.h) between
 // rt_upload_scene / rt_adopt_scene_blob and rt_shutdown; work buffers (frame, per-depth fold
 // records, counters) grow on demand and are reused across calls, one set per lane (a stream
-// with its own buffers: launches on the two lanes may overlap on the GPU).  There is no CPU fallback:
+// with its own buffers: launches on different lanes may overlap on the GPU).  There is no CPU fallback:
 // every entry point that needs the GPU fails with an error when HIP does.
 #include "../../include/rt_amd.h"
 
@@ -39,7 +39,7 @@ struct Lane {
     uint32_t* d_region_order = nullptr; uint32_t* d_region_cost = nullptr; uint32_t region_cap = 0;
     RegionKey region_key{}; bool region_key_valid = false;
 };
-constexpr int N_LANES = 2;
+constexpr int N_LANES = RT_LANES;
 
 struct State {
     bool inited = false;
@@ -430,7 +430,7 @@ int rt_pack_rgb(const uint32_t* d_pixels, uint32_t width, uint32_t height, uint8
 
 int rt_select_lane(int lane) {
     if (!g.inited) return fail("rt_init has not been called");
-    if (lane < 0 || lane >= N_LANES) return fail("rt_select_lane: there are two lanes, 0 and 1");
+    if (lane < 0 || lane >= N_LANES) return fail("rt_select_lane: the lanes are 0 .. " + std::to_string(N_LANES - 1));
     g.lane = lane;
     return 0;
 }

@@ -7,10 +7,12 @@ rank 0 and replicated with one broadcast; every frame ends with one gather of th
 per-rank row buffers to rank 0, which scatters them back into frame order.  No other
 collective is involved.
 
-Frames are pipelined two deep over the library's two lanes (a stream with its own work buffers
-each): frame i+1 is enqueued on the other lane than frame i, so its kernel fills the GPU while
-the kernel of frame i drains and the gather of frame i is in flight; rank 0 restores frame order
-of a frame when its lane is used again (or at flush()).
+Frames are pipelined over the library's lanes (a stream with its own work buffers each), two
+deep up to four ranks and four deep beyond: frame i+1 is enqueued on the next lane, so its kernel
+fills the GPU while the kernel of frame i drains and the gather of frame i is in flight; rank 0
+restores frame order of a frame when its lane comes round again (or at flush()).  The smaller a
+rank's share of the frame, the more of its launch is the tail of its slowest wavefronts, and the
+more frames in flight it takes to fill the GPU.
 
 The index arithmetic and the pipelining logic do not need a GPU: ShardedRenderer takes the two
 device operations (render my tiles, restore frame order) as callables, so the same class runs
@@ -19,6 +21,14 @@ under the gloo backend on CPU tensors in the tests.
 import numpy as np
 
 from . import TILE_ROWS
+
+MAX_LANES = 4                      # lanes of the library (RT_LANES)
+
+
+def default_lanes(world):
+    """Frames in flight per GPU when the frame is cut over `world` ranks (measured on the 4K dragon frame: a
+    quarter of the frame fills the GPU with two launches in flight, an eighth needs four)."""
+    return 2 if world <= 4 else 4
 
 
 def shard_row_indices(height, shard, nshards, tile_rows=TILE_ROWS):
@@ -60,13 +70,13 @@ class ShardedRenderer:
 
     render_rows(frame_desc, rank, world, tile_rows, out[stride, W])   enqueue this rank's tiles
     assemble(gathered[world, stride, W], frame_out[H, W], tile_rows)  restore frame order (rank 0)
-    select_lane(lane)                                                 make `lane` (0 or 1) the one the two operations above use
+    select_lane(lane)                                                 make `lane` the one the two operations above use
     stream_ctx(lane)                                                  context manager entered around everything enqueued for `lane`
 
-    Consecutive frames alternate between two lanes, each with its own stream and buffers, so the work of
+    Consecutive frames cycle through `lanes` lanes, each with its own stream and buffers, so the work of
     frame i+1 does not wait for frame i: its kernel fills the GPU while the kernel of frame i drains, and the
     gather of frame i overlaps it.  The tensor render_frame returns holds its frame once flush() has been called
-    (or two more frames have been enqueued) and the device has been synchronised.
+    (or `lanes` more frames have been enqueued) and the device has been synchronised.
     """
 
     def __init__(self, device, render_rows, assemble, stream_ctx=None, tile_rows=TILE_ROWS, always_gather=False, select_lane=None, lanes=None):
@@ -82,28 +92,29 @@ class ShardedRenderer:
         self._stream_ctx = stream_ctx or (lambda lane: contextlib.nullcontext())
         self._select_lane = select_lane or (lambda lane: None)
         self._bufs = {}
-        self._pending = [None, None]    # per lane: (work, W, H) of the frame whose gather is in flight
+        self._pending = [None] * MAX_LANES    # per lane: (work, W, H) of the frame whose gather is in flight
         self._slot = 0
         # A single rank normally renders straight into the frame; with always_gather it goes through
         # the same gather and reassembly as many ranks do (to rehearse that path on one GPU).
         self._collectives = self.world > 1 or (always_gather and dist.is_initialized())
         # A single rank without collectives keeps to one lane unless asked otherwise: its launches then run one
         # after the other, and a launch's duration is the time of a frame.
-        self.lanes = lanes if lanes is not None else (2 if self._collectives else 1)
-        assert self.lanes in (1, 2)
+        self.lanes = lanes if lanes is not None else (default_lanes(self.world) if self._collectives else 1)
+        assert 1 <= self.lanes <= MAX_LANES
 
     def buffers(self, width, height):
-        """(stride, local[2], gathered[2], frame[2]): one set per lane."""
+        """(stride, local[lanes], gathered[lanes], frame[lanes]): one set per lane."""
         key = (width, height)
         if key not in self._bufs:
             torch = self.torch
             stride = max_shard_rows(height, self.world, self.tile_rows)
-            local = [torch.zeros((stride, width), dtype=torch.int32, device=self.device) for _ in range(2)]
-            gathered, frame = [None, None], [None, None]
+            L = self.lanes
+            local = [torch.zeros((stride, width), dtype=torch.int32, device=self.device) for _ in range(L)]
+            gathered, frame = [None] * L, [None] * L
             if self.rank == 0:
-                frame = [torch.zeros((height, width), dtype=torch.int32, device=self.device) for _ in range(2)]
+                frame = [torch.zeros((height, width), dtype=torch.int32, device=self.device) for _ in range(L)]
                 if self._collectives:
-                    gathered = [torch.zeros((self.world, stride, width), dtype=torch.int32, device=self.device) for _ in range(2)]
+                    gathered = [torch.zeros((self.world, stride, width), dtype=torch.int32, device=self.device) for _ in range(L)]
             self._bufs[key] = (stride, local, gathered, frame)
         return self._bufs[key]
 
@@ -127,14 +138,13 @@ class ShardedRenderer:
         W, H = frame_desc.width, frame_desc.height
         stride, local, gathered, frame = self.buffers(W, H)
         lane = self._slot
-        if self.lanes == 2:
-            self._slot ^= 1
+        self._slot = (self._slot + 1) % self.lanes
         self._select_lane(lane)
         with self._stream_ctx(lane):
             if not self._collectives:
                 self._render_rows(frame_desc, 0, 1, self.tile_rows, frame[lane])
                 return frame[lane]
-            # the frame rendered on this lane two frames ago: its gather has had two kernels' time to finish
+            # the frame rendered on this lane `lanes` frames ago: its gather has had that many kernels' time to finish
             self._complete(lane)
             self._render_rows(frame_desc, self.rank, self.world, self.tile_rows, local[lane])
             work = self.dist.gather(local[lane], list(gathered[lane].unbind(0)) if self.rank == 0 else None, dst=0, async_op=True)
@@ -142,7 +152,7 @@ class ShardedRenderer:
         return frame[lane]
 
     def flush(self):
-        for lane in (self._slot, self._slot ^ 1):          # oldest first
+        for lane in [(self._slot + k) % self.lanes for k in range(self.lanes)]:          # oldest first
             self._select_lane(lane)
             with self._stream_ctx(lane):
                 self._complete(lane)
@@ -158,7 +168,7 @@ def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gathe
     torch.cuda.set_device(device)
     rt.init(device_index)
     ext = []                                                           # torch work is ordered on the library's streams, one per lane
-    for lane in (0, 1):
+    for lane in range(MAX_LANES):
         rt.select_lane(lane)
         ext.append(torch.cuda.ExternalStream(rt.stream(), device=device))
     rt.select_lane(0)

@@ -98,7 +98,7 @@ extern "C" {
     pub fn rt_pack_rgb(d_pixels: *const u32, width: u32, height: u32, d_rgb: *mut u8) -> c_int;
     pub fn rt_assemble_tiles(d_gathered: *const u32, rows_per_shard_stride: u32, nshards: u32, tile_rows: u32, width: u32, height: u32,
                              d_frame: *mut u32) -> c_int;
-    /// Two lanes (stream + work buffers each); launches on different lanes may overlap on the GPU.
+    /// `RT_LANES` = 4 lanes (stream + work buffers each); launches on different lanes may overlap on the GPU.
     pub fn rt_select_lane(lane: c_int) -> c_int;
     pub fn rt_stream() -> *mut c_void;
     pub fn rth_load_config_file(path: *const c_char) -> *mut rth_config;

@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, width, height, tile_rows, out_path):
+def _worker(rank, world, port, width, height, tile_rows, lanes, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     for p in (ROOT, os.path.join(ROOT, "oracle")):
@@ -67,9 +67,10 @@ def _worker(rank, world, port, width, height, tile_rows, out_path):
         class FrameDesc:
             pass
 
-        renderer = shard.ShardedRenderer(torch.device("cpu"), render_rows, assemble, tile_rows=tile_rows)
+        renderer = shard.ShardedRenderer(torch.device("cpu"), render_rows, assemble, tile_rows=tile_rows, lanes=lanes)
+        lanes = renderer.lanes
         outs = []
-        sizes = [(width, height), (width, height), (width, height), (width // 2, height)]       # four frames through the two lanes
+        sizes = [(width, height)] * (lanes + 1) + [(width // 2, height)]       # more frames than lanes, and another size
         for w, h in sizes:
             fd = FrameDesc()
             fd.width, fd.height = w, h
@@ -77,20 +78,20 @@ def _worker(rank, world, port, width, height, tile_rows, out_path):
         renderer.flush()
         if rank == 0:
             ok = True
-            for w, h, out in outs[1:]:          # the first full-size frame's tensor was reused by the third
+            for w, h, out in outs[1:]:          # the first frame's tensor was used again when its lane came round
                 want, _ = sc.render(width=w, height=h, threads=2)
                 ok = ok and np.array_equal(out.numpy().view(np.uint32), want)
-            ok = ok and outs[0][2] is outs[2][2] and outs[0][2] is not outs[1][2]
+            ok = ok and outs[0][2] is outs[lanes][2] and all(outs[0][2] is not outs[k][2] for k in range(1, lanes))
             np.save(out_path, np.array([int(ok)]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,width,height,tile_rows", [(2, 96, 70, 8), (3, 64, 50, 8), (2, 40, 9, 16)])
-def test_sharded_frame_over_gloo(tmp_path, world, width, height, tile_rows):
+@pytest.mark.parametrize("world,width,height,tile_rows,lanes", [(2, 96, 70, 8, None), (3, 64, 50, 8, None), (2, 40, 9, 16, None), (2, 64, 40, 8, 4), (2, 64, 40, 8, 1)])
+def test_sharded_frame_over_gloo(tmp_path, world, width, height, tile_rows, lanes):
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_worker, args=(world, _free_port(), width, height, tile_rows, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), width, height, tile_rows, lanes, out), nprocs=world, join=True)
     assert np.load(out)[0] == 1
 
 

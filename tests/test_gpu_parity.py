@@ -463,31 +463,30 @@ def test_tiny_and_empty_scenes(text):
         assert (got["primary"], got["shadow"], got["secondary"]) == (st["primary"], st["shadow"], st["secondary"])
 
 
-def test_two_lanes_render_different_frames_at_once():
-    """Launches on the two lanes overlap on the GPU and must not share work buffers: two different frames
-    enqueued back to back, several times over, equal their renders one at a time."""
+def test_lanes_render_different_frames_at_once():
+    """Launches on different lanes overlap on the GPU and must not share work buffers: different frames
+    enqueued back to back on all lanes, several times over, equal their renders one at a time."""
     import torch
     cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
     cfg.set_size(1283, 721)
     rt.RayTracer(cfg)
-    fa = cfg.frame()
-    fb = rt.frame_from_camera((9.0, 13.0, 12.0), (0.0, 5.0, -1.0), (0.0, 1.0, 0.0), 50.0, 1283, 721, 4, (0.0, 0.0, 0.0))
+    frames = [cfg.frame()]
+    for k in range(1, rt.LANES):
+        frames.append(rt.frame_from_camera((9.0 - 3.0 * k, 13.0, 12.0), (0.0, 5.0, -1.0), (0.0, 1.0, 0.0), 50.0, 1283, 721, 2 + k, (0.0, 0.0, 0.0)))
     rt.select_lane(0)
-    want_a, _ = rt.render(fa)
-    want_b, _ = rt.render(fb)
-    assert not np.array_equal(want_a, want_b)
-    bufs = [torch.zeros((721, 1283), dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    want = [rt.render(f)[0] for f in frames]
+    assert all(not np.array_equal(want[0], w) for w in want[1:])
+    bufs = [torch.zeros((721, 1283), dtype=torch.int32, device="cuda:0") for _ in range(rt.LANES)]
     try:
         for _ in range(4):
-            rt.select_lane(0)
-            rt.render_tiles(fa, 0, 1, bufs[0].data_ptr())
-            rt.select_lane(1)
-            rt.render_tiles(fb, 0, 1, bufs[1].data_ptr())
+            for lane in range(rt.LANES):
+                rt.select_lane(lane)
+                rt.render_tiles(frames[lane], 0, 1, bufs[lane].data_ptr())
         torch.cuda.synchronize()
-        assert np.array_equal(bufs[0].cpu().numpy().view(np.uint32), want_a)
-        assert np.array_equal(bufs[1].cpu().numpy().view(np.uint32), want_b)
-        with pytest.raises(rt.RtError, match="two lanes"):
-            rt.select_lane(2)
+        for lane in range(rt.LANES):
+            assert np.array_equal(bufs[lane].cpu().numpy().view(np.uint32), want[lane]), lane
+        with pytest.raises(rt.RtError, match="lanes are 0 .. 3"):
+            rt.select_lane(rt.LANES)
     finally:
         rt.select_lane(0)
 
