@@ -92,6 +92,7 @@ class ShardedRenderer:
         self._stream_ctx = stream_ctx or (lambda lane: contextlib.nullcontext())
         self._select_lane = select_lane or (lambda lane: None)
         self._bufs = {}
+        self._gather_lists = {}         # per frame size and lane: the per-rank views of the gather buffer, made once
         self._pending = [None] * MAX_LANES    # per lane: (work, W, H) of the frame whose gather is in flight
         self._slot = 0
         # A single rank normally renders straight into the frame; with always_gather it goes through
@@ -147,7 +148,12 @@ class ShardedRenderer:
             # the frame rendered on this lane `lanes` frames ago: its gather has had that many kernels' time to finish
             self._complete(lane)
             self._render_rows(frame_desc, self.rank, self.world, self.tile_rows, local[lane])
-            work = self.dist.gather(local[lane], list(gathered[lane].unbind(0)) if self.rank == 0 else None, dst=0, async_op=True)
+            views = None
+            if self.rank == 0:
+                views = self._gather_lists.get((W, H, lane))
+                if views is None:
+                    views = self._gather_lists[(W, H, lane)] = list(gathered[lane].unbind(0))
+            work = self.dist.gather(local[lane], views, dst=0, async_op=True)
             self._pending[lane] = (work, W, H)
         return frame[lane]
 
