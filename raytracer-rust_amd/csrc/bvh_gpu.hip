@@ -143,15 +143,16 @@ __device__ __forceinline__ float half_area3(const float* l, const float* h) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-struct Grid { float origin[3], scale[3], pad_abs; };
+struct Grid { float origin[3], scale[3], inv_scale[3], pad_abs; };
 
 // Outward padding as the host builder applies it, then outward rounding onto the 16-bit grid with one
 // extra step of margin for the rounding of this very computation.
 __device__ __forceinline__ void quantise_box(const Grid& g, const float* l, const float* h, rtl::QuantChild* out) {
     for (int k = 0; k < 3; k++) {
         const float pad = fmaxf(fabsf(l[k]), fabsf(h[k])) * 4e-7f + g.pad_abs;
-        const float ql = floorf((l[k] - pad - g.origin[k]) / g.scale[k]) - 1.0f;
-        const float qh = ceilf((h[k] + pad - g.origin[k]) / g.scale[k]) + 1.0f;
+        // (times the rounded reciprocal: off by less than a hundredth of a step at the far end of the grid, the extra step covers it)
+        const float ql = floorf((l[k] - pad - g.origin[k]) * g.inv_scale[k]) - 1.0f;
+        const float qh = ceilf((h[k] + pad - g.origin[k]) * g.inv_scale[k]) + 1.0f;
         out->lo[k] = (uint16_t)fminf(fmaxf(ql, 0.0f), rtl::GRID_STEPS);
         out->hi[k] = (uint16_t)fminf(fmaxf(qh, 0.0f), rtl::GRID_STEPS);
     }
@@ -165,14 +166,16 @@ struct Bins {                            // per axis and bin: box of the shapes 
     uint32_t lo[3][BINS][3], hi[3][BINS][3], cnt[3][BINS];
 };
 
-__device__ __forceinline__ int bin_of(float lo, float hi, float origin, float scale) {
+// nb: bins in use per axis (BINS for large nodes; small nodes take fewer, as the host builder does: most nodes of a
+// tree hold a handful of shapes, and clearing and sweeping all bins for each of them would be most of the work).
+__device__ __forceinline__ int bin_of(float lo, float hi, float origin, float scale, int nb = BINS) {
     const int b = (int)((0.5f * lo + 0.5f * hi - origin) * scale);
-    return min(max(b, 0), BINS - 1);
+    return min(max(b, 0), nb - 1);
 }
 
-__device__ __forceinline__ void bin_scales(const float* clo, const float* chi, float* inv) {
+__device__ __forceinline__ void bin_scales(const float* clo, const float* chi, float* inv, int nb = BINS) {
     for (int k = 0; k < 3; k++) {
-        inv[k] = chi[k] > clo[k] ? (float)BINS * 0.999999f / (chi[k] - clo[k]) : 0.0f;
+        inv[k] = chi[k] > clo[k] ? (float)nb * 0.999999f / (chi[k] - clo[k]) : 0.0f;
         if (!(inv[k] < INFINITY)) inv[k] = 0.0f;
     }
 }
@@ -180,14 +183,14 @@ __device__ __forceinline__ void bin_scales(const float* clo, const float* chi, f
 // Cheapest split "bins 0..b of axis ax to the left" over all axes with a usable scale, candidates spread over the
 // lanes of the calling wavefront.  Every lane returns the same: *best = sum over the sides of area x count (INFINITY
 // when nothing separates), result = ax * BINS + b or -1.
-__device__ int best_split(const Bins& bins, const float* inv, uint32_t lane, float* best_out) {
+__device__ int best_split(const Bins& bins, const float* inv, uint32_t lane, float* best_out, int nb = BINS) {
     float best = INFINITY; int best_id = -1;
     for (uint32_t cand = lane; cand < 3u * BINS; cand += 64) {
         const uint32_t ax = cand / BINS, b = cand % BINS;
-        if (b + 1 < BINS && inv[ax] != 0.0f) {
+        if (b + 1 < (uint32_t)nb && inv[ax] != 0.0f) {
             float l0[3] = {INFINITY, INFINITY, INFINITY}, h0[3] = {-INFINITY, -INFINITY, -INFINITY}, l1[3] = {INFINITY, INFINITY, INFINITY}, h1[3] = {-INFINITY, -INFINITY, -INFINITY};
             uint32_t n0 = 0, n1 = 0;
-            for (uint32_t q = 0; q < (uint32_t)BINS; q++) {
+            for (uint32_t q = 0; q < (uint32_t)nb; q++) {
                 const uint32_t c = bins.cnt[ax][q];
                 if (c == 0u) continue;
                 for (int k = 0; k < 3; k++) {
@@ -209,6 +212,8 @@ __device__ int best_split(const Bins& bins, const float* inv, uint32_t lane, flo
     *best_out = __shfl(best, 0, 64);
     return __shfl(best_id, 0, 64);                                     // one decision for the whole wavefront
 }
+
+__device__ __forceinline__ float first_lane(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 // Halving by position instead of a split search: when the levels a balanced subtree still needs (leaves of
 // MAX_LEAF shapes) would otherwise not fit under the depth limit.
@@ -526,36 +531,41 @@ __global__ __launch_bounds__(64) void build_groups(GroupList groups, uint32_t n_
                 lo[k] = fminf(lo[k], l); hi[k] = fmaxf(hi[k], h); clo[k] = fminf(clo[k], ctr); chi[k] = fmaxf(chi[k], ctr);
             }
         }
-        for (int off = 32; off > 0; off >>= 1)
+        // The node's shapes sit in lanes 0 .. min(m, 64) - 1: the butterfly only needs the levels that span them (most
+        // nodes hold a handful of shapes), and lane 0 then holds the result for everyone.
+        const int top = m > 32u ? 32 : m > 1u ? 1 << (31 - __clz((int)m - 1)) : 0;
+        for (int off = top; off > 0; off >>= 1)
             for (int k = 0; k < 3; k++) {
                 lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
                 clo[k] = fminf(clo[k], __shfl_xor(clo[k], off, 64)); chi[k] = fmaxf(chi[k], __shfl_xor(chi[k], off, 64));
             }
+        for (int k = 0; k < 3; k++) { lo[k] = first_lane(lo[k]); hi[k] = first_lane(hi[k]); clo[k] = first_lane(clo[k]); chi[k] = first_lane(chi[k]); }
         const float area = half_area3(lo, hi);
         const bool halve = must_halve(depth, m, depth_limit);
         bool make_leaf = m == 1u || (halve && m <= rtl::MAX_LEAF);
-        int axis = -1; uint32_t split_bin = 0; float scale = 0.0f, origin = 0.0f;
+        int axis = -1, nb = BINS; uint32_t split_bin = 0; float scale = 0.0f, origin = 0.0f;
         if (!make_leaf && !halve) {
-            for (uint32_t j = lane; j < 3u * BINS; j += 64) {
-                const uint32_t ax = j / BINS, b = j % BINS;
+            nb = m <= 8u ? 4 : m <= 32u ? 8 : BINS;
+            for (uint32_t j = lane; j < 3u * (uint32_t)nb; j += 64) {
+                const uint32_t ax = j / (uint32_t)nb, b = j % (uint32_t)nb;
                 for (int k = 0; k < 3; k++) { bins.lo[ax][b][k] = 0xFFFFFFFFu; bins.hi[ax][b][k] = 0u; }
                 bins.cnt[ax][b] = 0u;
             }
             __syncthreads();
             float inv[3];
-            bin_scales(clo, chi, inv);
+            bin_scales(clo, chi, inv, nb);
             for (uint32_t j = lane; j < m; j += 64) {
                 const uint32_t s = perm[start + j];
                 for (int ax = 0; ax < 3; ax++) {
                     if (inv[ax] == 0.0f) continue;
-                    const int b = bin_of(blo[ax][s], bhi[ax][s], clo[ax], inv[ax]);
+                    const int b = bin_of(blo[ax][s], bhi[ax][s], clo[ax], inv[ax], nb);
                     for (int k = 0; k < 3; k++) { atomicMin(&bins.lo[ax][b][k], ordered(blo[k][s])); atomicMax(&bins.hi[ax][b][k], ordered(bhi[k][s])); }
                     atomicAdd(&bins.cnt[ax][b], 1u);
                 }
             }
             __syncthreads();
             float best;
-            const int best_id = best_split(bins, inv, lane, &best);
+            const int best_id = best_split(bins, inv, lane, &best, nb);
             if (best_id >= 0) {
                 const float split_cost = COST_BOX + COST_SHAPE * (area > 0.0f ? best / area : (float)m);
                 if (m <= rtl::MAX_LEAF && COST_SHAPE * (float)m <= split_cost) make_leaf = true;
@@ -576,14 +586,14 @@ __global__ __launch_bounds__(64) void build_groups(GroupList groups, uint32_t n_
             for (uint32_t base = 0; base < m; base += 64) {
                 const uint32_t j = base + lane;
                 bool left = false;
-                if (j < m) { const uint32_t s = perm[start + j]; left = (uint32_t)bin_of(blo[axis][s], bhi[axis][s], origin, scale) <= split_bin; }
+                if (j < m) { const uint32_t s = perm[start + j]; left = (uint32_t)bin_of(blo[axis][s], bhi[axis][s], origin, scale, nb) <= split_bin; }
                 nl += (uint32_t)__popcll(__ballot(left));
             }
             uint32_t at_left = 0, at_right = nl;
             for (uint32_t base = 0; base < m; base += 64) {
                 const uint32_t j = base + lane;
                 bool left = false, right = false; uint32_t s = 0;
-                if (j < m) { s = perm[start + j]; left = (uint32_t)bin_of(blo[axis][s], bhi[axis][s], origin, scale) <= split_bin; right = !left; }
+                if (j < m) { s = perm[start + j]; left = (uint32_t)bin_of(blo[axis][s], bhi[axis][s], origin, scale, nb) <= split_bin; right = !left; }
                 const unsigned long long ml = __ballot(left), mr = __ballot(right), below = (1ull << lane) - 1ull;
                 if (left) scratch[at_left + (uint32_t)__popcll(ml & below)] = (uint16_t)s;
                 if (right) scratch[at_right + (uint32_t)__popcll(mr & below)] = (uint16_t)s;
@@ -603,11 +613,12 @@ __global__ __launch_bounds__(64) void build_groups(GroupList groups, uint32_t n_
                 else { l1[k] = fminf(l1[k], blo[k][s]); h1[k] = fmaxf(h1[k], bhi[k][s]); }
             }
         }
-        for (int off = 32; off > 0; off >>= 1)
+        for (int off = top; off > 0; off >>= 1)
             for (int k = 0; k < 3; k++) {
                 l0[k] = fminf(l0[k], __shfl_xor(l0[k], off, 64)); h0[k] = fmaxf(h0[k], __shfl_xor(h0[k], off, 64));
                 l1[k] = fminf(l1[k], __shfl_xor(l1[k], off, 64)); h1[k] = fmaxf(h1[k], __shfl_xor(h1[k], off, 64));
             }
+        for (int k = 0; k < 3; k++) { l0[k] = first_lane(l0[k]); h0[k] = first_lane(h0[k]); l1[k] = first_lane(l1[k]); h1[k] = first_lane(h1[k]); }
         const uint32_t slot = next_slot++;
         if (lane == 0) {
             rtl::QuantPair p;
@@ -720,7 +731,7 @@ BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltSc
         float sc = (float)(((double)(hi + pad) - (double)g.origin[k]) / (double)rtl::GRID_STEPS);
         sc = nextafterf(nextafterf(sc, INFINITY), INFINITY);
         if (!(sc > 1e-30f)) sc = 1e-30f;
-        g.scale[k] = sc; h.grid_origin[k] = g.origin[k]; h.grid_scale[k] = sc;
+        g.scale[k] = sc; g.inv_scale[k] = 1.0f / sc; h.grid_origin[k] = g.origin[k]; h.grid_scale[k] = sc;
     }
     float root_area = ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0];
     if (!std::isfinite(root_area)) root_area = 0.0f;
