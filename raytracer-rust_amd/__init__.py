@@ -506,6 +506,9 @@ def stream():
     return lib().rt_stream()
 
 
+GPU_BUILD_FROM = 200_000      # shapes from which from_scene_file builds the tree on the GPU unless told otherwise
+
+
 class RayTracer:
     """RayTracer of raytracer.rs:16-83 on one MI355X."""
 
@@ -522,10 +525,12 @@ class RayTracer:
         return cls(config)
 
     @classmethod
-    def from_scene_file(cls, path, cache_path=None, device=None):
+    def from_scene_file(cls, path, cache_path=None, device=None, gpu_build=None):
         """main.rs:9-11 with a binary cache beside the scene file: the first start parses the text,
         builds the tree and writes `cache_path` (default: path + ".rtcache"); later starts map the
-        cache and upload it, as long as the scene file is unchanged."""
+        cache and upload it, as long as the scene file is unchanged.  gpu_build: where the tree is built
+        on the first start (None: on the GPU from GPU_BUILD_FROM shapes on, where the host builder takes
+        longer than everything else put together; the frame does not depend on it)."""
         if _bound_device is None:
             init(0 if device is None else device)
         cache_path = cache_path or (os.fspath(path) + ".rtcache")
@@ -546,7 +551,9 @@ class RayTracer:
             cache.close()
         self.config = ParsedConfigState().load_config_file(path)
         self._scene = self.config.scene()
-        self.bvh_info = upload_scene(self._scene)
+        if gpu_build is None:
+            gpu_build = self._scene.ntri + self._scene.nsph >= GPU_BUILD_FROM
+        self.bvh_info = upload_scene(self._scene, gpu_build=gpu_build)
         SceneCache.write(cache_path, self.config, download_scene_blob(), source_path=path)
         self.from_cache = False
         return self
