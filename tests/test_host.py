@@ -37,6 +37,38 @@ def test_library_exports_every_declared_symbol():
     assert names == set(rt._SIGNATURES), "python binding table and headers disagree"
 
 
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: both headers compile as strict C99, and the calling sequence a C host
+    would write type-checks against them."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    src = tmp_path / "host.c"
+    src.write_text("""
+#include <stdio.h>
+#include <stdlib.h>
+#include "rt_amd.h"
+#include "rt_host.h"
+int main(void) {
+    rth_config* cfg = rth_load_config_file("x.scene");
+    rt_scene scene; rt_frame frame; rt_stats stats; rt_bvh_info info;
+    if (!cfg) { fprintf(stderr, "%s\\n", rt_last_error()); return 1; }
+    rth_config_scene(cfg, &scene); rth_config_frame(cfg, &frame);
+    rt_init(0); rt_upload_scene_ex(&scene, RT_BUILD_ON_GPU); rt_get_bvh_info(&info);
+    { uint32_t* pixels = malloc(4ull * frame.width * frame.height);
+      if (rt_render(&frame, pixels, &stats, 0)) fprintf(stderr, "%s\\n", rt_last_error());
+      free(pixels); }
+    rt_select_lane(RT_LANES - 1);
+    rt_shutdown(); rth_config_free(cfg);
+    return 0;
+}
+""")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_render_without_init_fails_loudly():
     # No CPU fallback: without a bound GPU the render entry point reports an error.
     f = rt.frame_from_camera((0, 0, 0), (0, 0, 1), (0, 1, 0), 60, 8, 8, 1, (0, 0, 0))
