@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIBRARY") or os.path.join(_HERE, "librt_amd.so")   # the override serves side-by-side builds of the kernels
 
 TILE_ROWS = 8   # rows per interleaved tile when a frame is sharded over GPUs
 

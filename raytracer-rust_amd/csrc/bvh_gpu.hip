@@ -145,7 +145,7 @@ __device__ __forceinline__ float half_area3(const float* l, const float* h) {
 
 struct Grid { float origin[3], scale[3], inv_scale[3], pad_abs; };
 
-// Outward padding as the host builder applies it, then outward rounding onto the 16-bit grid with one
+// Outward padding as the host builder applies it, then outward rounding onto the 15-bit grid with one
 // extra step of margin for the rounding of this very computation.
 __device__ __forceinline__ void quantise_box(const Grid& g, const float* l, const float* h, rtl::QuantChild* out) {
     for (int k = 0; k < 3; k++) {
@@ -153,8 +153,8 @@ __device__ __forceinline__ void quantise_box(const Grid& g, const float* l, cons
         // (times the rounded reciprocal: off by less than a hundredth of a step at the far end of the grid, the extra step covers it)
         const float ql = floorf((l[k] - pad - g.origin[k]) * g.inv_scale[k]) - 1.0f;
         const float qh = ceilf((h[k] + pad - g.origin[k]) * g.inv_scale[k]) + 1.0f;
-        out->lo[k] = (uint16_t)fminf(fmaxf(ql, 0.0f), rtl::GRID_STEPS);
-        out->hi[k] = (uint16_t)fminf(fmaxf(qh, 0.0f), rtl::GRID_STEPS);
+        out->q[k][0] = (uint16_t)fminf(fmaxf(ql, 0.0f), rtl::GRID_STEPS);
+        out->q[k][1] = (uint16_t)fminf(fmaxf(qh, 0.0f), rtl::GRID_STEPS);
     }
 }
 

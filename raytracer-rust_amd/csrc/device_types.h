@@ -7,7 +7,7 @@
 
 // Pointers into the resident scene blob (layout.h).
 struct DevScene {
-    const uint4* nodes;     // 2 uint4 per node pair: {lo.x|lo.y<<16, lo.z|hi.x<<16, hi.y|hi.z<<16, ref} per child
+    const uint4* nodes;     // 2 uint4 per node pair: {lo.x|hi.x<<16, lo.y|hi.y<<16, lo.z|hi.z<<16, ref} per child
     const float4* tree;     // 3 float4 per tree shape, leaves contiguous
     const float4* list;     // 3 float4 per always-tested shape
     const float4* mats;     // 2 float4 per material
@@ -15,6 +15,7 @@ struct DevScene {
     uint32_t n_list, n_lights, root_ref;
     uint32_t finite_shading;   // 1 when every material and light value is finite (lets zero contributions be skipped)
     float grid_origin[3], grid_scale[3];   // node box coordinate q on axis k = grid_origin[k] + q * grid_scale[k]
+    float inv_limit[3];                    // bound on |1 / direction| per axis that keeps grid_scale / direction and its multiples finite
 };
 
 // rt_frame plus the shard this launch renders.
@@ -46,6 +47,22 @@ inline uint32_t region_log2_for(uint64_t tiles) {
     uint32_t l = 3;
     while ((tiles >> (2 * l)) > 3072u && l < 12u) l++;     // leaves room for the partial regions at the frame's edges
     return l;
+}
+
+// LDS of one wavefront of the render kernel: a traversal stack of one entry per tree level plus a sentinel
+// (256 bytes per entry), and, when they fit beside it, the records of the reflection levels (maxdepth - 1 levels of
+// 1 KiB).  10 KiB per wavefront is what lets four wavefronts per SIMD share the 160 KiB of a compute unit; a frame
+// whose records do not fit keeps them in a global array instead (rtk_fold_in_lds says which).
+constexpr uint32_t RT_LDS_PER_WAVE = 10240;
+inline uint32_t rtk_stack_entries(int stack_depth) { return (uint32_t)(stack_depth < 7 ? 8 : stack_depth + 1); }
+inline bool rtk_fold_in_lds(int stack_depth, uint32_t maxdepth) {
+#ifdef RT_FOLD_GLOBAL
+    return false;
+#else
+    if (maxdepth <= 1) return true;                    // no records at all
+    const uint64_t levels = (uint64_t)maxdepth - 1u;
+    return levels <= 8 && (uint64_t)rtk_stack_entries(stack_depth) * 256u + levels * 1024u <= RT_LDS_PER_WAVE;
+#endif
 }
 
 // regions[order[i]] by decreasing cost into `order` (n <= MAX_SORTED_REGIONS), ties by index.

@@ -7,13 +7,16 @@
 //
 // every section 256-byte aligned.
 //
-//   node pair  32 B  two 16-byte child records side by side: {lo.xyz, hi.xyz as 16-bit grid
-//                    coordinates, ref}.  The grid spans the box of all tree shapes with 65535
-//                    steps per axis (header: grid_origin, grid_scale); a coordinate q stands for
-//                    the plane origin + q * scale.  Boxes are rounded outwards onto the grid, so
-//                    they only grow (by less than one step: 0.0015 % of the scene extent).  One
-//                    16-byte load per child instead of two: the vector memory pipeline, not HBM,
-//                    is what bounds traversal of a cache-resident scene.
+//   node pair  32 B  two 16-byte child records side by side: {lo.x | hi.x << 16, lo.y | hi.y << 16,
+//                    lo.z | hi.z << 16, ref}, coordinates on a 15-bit grid.  The grid spans the box
+//                    of all tree shapes with 32767 steps per axis (header: grid_origin, grid_scale);
+//                    a coordinate q stands for the plane origin + q * scale.  Boxes are rounded
+//                    outwards onto the grid, so they only grow (by less than one step: 0.003 % of
+//                    the scene extent).  15 bits, so that one byte permute turns a coordinate into
+//                    the float 32768 + q (bytes {0, q.lo, q.hi, 0x47}) with no integer-to-float
+//                    conversion, and low and high plane of an axis share a word, so that the same
+//                    permute, with a per-ray selector, also sorts them into the plane the ray
+//                    enters through and the one it leaves through.  One 16-byte load per child.
 //   shape      48 B  three float4.  q0.w carries kind | material << 2, q1.w the shape's
 //                    position in the scene file (tie break), q2.w is spare.
 //                      triangle: q0.xyz = v0, q1.xyz = v1, q2.xyz = v2   (raw vertices: the
@@ -45,10 +48,10 @@ struct ChildBox { float lo[3]; uint32_t ref; float hi[3]; uint32_t count; };
 struct NodePair { ChildBox c[2]; };
 static_assert(sizeof(NodePair) == 64, "builder node pair is 64 bytes");
 
-struct QuantChild { uint16_t lo[3], hi[3]; uint32_t ref; };
+struct QuantChild { uint16_t q[3][2]; uint32_t ref; };   // q[axis][0] = low plane, q[axis][1] = high plane
 struct QuantPair { QuantChild c[2]; };
 static_assert(sizeof(QuantChild) == 16 && sizeof(QuantPair) == 32, "device node pair must be 32 bytes");
-constexpr float GRID_STEPS = 65535.0f;
+constexpr float GRID_STEPS = 32767.0f;
 
 struct ShapeRec { float q0[3]; uint32_t kind_mat; float q1[3]; uint32_t order; float q2[3]; uint32_t spare; };
 static_assert(sizeof(ShapeRec) == 48, "shape record must be 48 bytes");
@@ -57,7 +60,7 @@ struct MaterialRec { float diffuse[3]; float shininess; float specular[3]; float
 struct LightRec { float v[3]; float kind; float color[3]; float pad; };
 
 constexpr uint32_t BLOB_MAGIC = 0x52544231u;   // "RTB1"
-constexpr uint32_t BLOB_VERSION = 2;
+constexpr uint32_t BLOB_VERSION = 3;
 
 struct BlobHeader {
     uint32_t magic, version;

@@ -33,7 +33,7 @@
 #pragma clang fp contract(off)
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 5
+#define RT_WAVES_PER_EU 4
 #endif
 #define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 
@@ -131,50 +131,69 @@ __device__ __forceinline__ bool shape_back_face(const float4 q0, const float4 q1
 }
 
 // ------------------------------------------------------------------ box culling (conservative)
-// Node boxes are 16-bit coordinates on the scene grid: plane q on an axis is origin + q * scale.
+// Node boxes are 15-bit coordinates on the scene grid: plane q on an axis is origin + q * scale.
 // Along a ray o + t d its parameter is (origin + q*scale - o) / d = q * A + B with, per ray and
-// axis, A = scale / d and B = (origin - o) / d, so one fused multiply-add per plane.  The
-// rounding of A, B and the multiply-add is bounded by delta = 2^-21 * (65535 |A| + |B|); B is
-// shifted by delta away from the interval on each side (the side is known from the sign of d),
-// so the computed interval always contains the exact one.  Nothing here decides a pixel: it
+// axis, A = scale / d and B = (origin - o) / d.  A child record keeps the low and the high plane
+// of an axis in one word; one byte permute per plane builds the float x = 32768 + q from it
+// (bytes {0, q.lo, q.hi, 0x47}: no integer-to-float conversion), and the ray's selector for that
+// permute already picks the plane the ray enters through (the low one when d >= 0) or the one it
+// leaves through, so no minimum / maximum per axis is needed afterwards.  The parameter is then
+// x * A + (B - 32768 A): one packed multiply-add gives entry and exit of an axis together.
+// The rounding of A, B, B - 32768 A, the shifted constant and the multiply-add is bounded by
+// delta = 2^-21 * (65535 |A| + |B|); the entry constant is lowered and the exit constant raised by
+// delta, so the computed interval always contains the exact one.  Nothing here decides a pixel: it
 // only has to keep every shape reachable that the exact tests would accept.
-struct RayBox { V3 A, Blo, Bhi; };
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct RayBox {
+    f2 Ax, Ay, Az;            // {A, A} per axis
+    f2 Bx, By, Bz;            // {entry constant, exit constant} per axis
+    uint32_t sel_in[3], sel_out[3];   // permute selectors: which half of the axis word is entered / left through
+};
 
-__device__ __forceinline__ float safe_inverse(float d) {
+__device__ __forceinline__ float safe_inverse(float d, float limit) {
     // A zero (or denormal) direction component would make A and B infinite and their sum NaN;
     // a huge finite slope keeps the slab semantics (inside: unbounded interval, outside: empty).
     float inv = 1.0f / d;
-    return fminf(fmaxf(inv, -1e30f), 1e30f);
+    return fminf(fmaxf(inv, -limit), limit);
+}
+
+__device__ __forceinline__ void make_axis(float scale, float origin, float limit, float o, float d, f2* A, f2* B, uint32_t* sel_in, uint32_t* sel_out) {
+    const float inv = safe_inverse(d, limit);
+    const float a = scale * inv;
+    const float b = fminf(fmaxf((origin - o) * inv, -1e37f), 1e37f);
+    const float delta = 4.76837158203125e-07f * (65535.0f * fabsf(a) + fabsf(b));      // 2^-21 (...)
+    const float shifted = b - 32768.0f * a;
+    *A = f2{a, a};
+    *B = f2{shifted - delta, shifted + delta};
+    // selector bytes, lowest first: 0x0C -> 0x00; 0/1 or 2/3 -> low or high half of the axis word; 7 -> 0x47 of the constant
+    const bool forward = inv >= 0.0f;
+    *sel_in = forward ? 0x0701000Cu : 0x0703020Cu;
+    *sel_out = forward ? 0x0703020Cu : 0x0701000Cu;
 }
 
 __device__ __forceinline__ RayBox make_raybox(const DevScene& sc, V3 o, V3 d) {
     RayBox r;
-    const V3 inv = v3(safe_inverse(d.x), safe_inverse(d.y), safe_inverse(d.z));
-    r.A = v3(sc.grid_scale[0] * inv.x, sc.grid_scale[1] * inv.y, sc.grid_scale[2] * inv.z);
-    const V3 B = v3((sc.grid_origin[0] - o.x) * inv.x, (sc.grid_origin[1] - o.y) * inv.y, (sc.grid_origin[2] - o.z) * inv.z);
-    const float k = 4.76837158203125e-07f;   // 2^-21
-    const V3 delta = v3(k * (65535.0f * fabsf(r.A.x) + fabsf(B.x)), k * (65535.0f * fabsf(r.A.y) + fabsf(B.y)),
-                        k * (65535.0f * fabsf(r.A.z) + fabsf(B.z)));
-    // For d >= 0 the low plane is entered first: lower it (B - delta) and raise the high one.
-    r.Blo = v3(inv.x >= 0.0f ? B.x - delta.x : B.x + delta.x, inv.y >= 0.0f ? B.y - delta.y : B.y + delta.y,
-               inv.z >= 0.0f ? B.z - delta.z : B.z + delta.z);
-    r.Bhi = v3(inv.x >= 0.0f ? B.x + delta.x : B.x - delta.x, inv.y >= 0.0f ? B.y + delta.y : B.y - delta.y,
-               inv.z >= 0.0f ? B.z + delta.z : B.z - delta.z);
+    make_axis(sc.grid_scale[0], sc.grid_origin[0], sc.inv_limit[0], o.x, d.x, &r.Ax, &r.Bx, &r.sel_in[0], &r.sel_out[0]);
+    make_axis(sc.grid_scale[1], sc.grid_origin[1], sc.inv_limit[1], o.y, d.y, &r.Ay, &r.By, &r.sel_in[1], &r.sel_out[1]);
+    make_axis(sc.grid_scale[2], sc.grid_origin[2], sc.inv_limit[2], o.z, d.z, &r.Az, &r.Bz, &r.sel_in[2], &r.sel_out[2]);
     return r;
 }
 
+__device__ __forceinline__ f2 planes_of(uint32_t axis_word, uint32_t sel_in, uint32_t sel_out) {
+    const uint32_t K = 0x47000000u;       // exponent byte of 32768 + q
+    return f2{__uint_as_float(__builtin_amdgcn_perm(K, axis_word, sel_in)), __uint_as_float(__builtin_amdgcn_perm(K, axis_word, sel_out))};
+}
+
 __device__ __forceinline__ bool slab(const uint4 c, const RayBox& rb, float tlim, float* tnear) {
-    const float lx = (float)(c.x & 0xFFFFu), ly = (float)(c.x >> 16), lz = (float)(c.y & 0xFFFFu);
-    const float hx = (float)(c.y >> 16), hy = (float)(c.z & 0xFFFFu), hz = (float)(c.z >> 16);
-    const float ax = fmaf(lx, rb.A.x, rb.Blo.x), bx = fmaf(hx, rb.A.x, rb.Bhi.x);
-    const float ay = fmaf(ly, rb.A.y, rb.Blo.y), by = fmaf(hy, rb.A.y, rb.Bhi.y);
-    const float az = fmaf(lz, rb.A.z, rb.Blo.z), bz = fmaf(hz, rb.A.z, rb.Bhi.z);
-    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const f2 tx = __builtin_elementwise_fma(planes_of(c.x, rb.sel_in[0], rb.sel_out[0]), rb.Ax, rb.Bx);
+    const f2 ty = __builtin_elementwise_fma(planes_of(c.y, rb.sel_in[1], rb.sel_out[1]), rb.Ay, rb.By);
+    const f2 tz = __builtin_elementwise_fma(planes_of(c.z, rb.sel_in[2], rb.sel_out[2]), rb.Az, rb.Bz);
+    const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
     // The limit goes in through a bare v_min_f32: the compiler would otherwise re-canonicalise it in every pass
     // (it cannot see through the loop that the value is never a signalling NaN).
     float zlim;
-    asm("v_min_f32 %0, %1, %2" : "=v"(zlim) : "v"(fmaxf(az, bz)), "v"(tlim));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), zlim);
+    asm("v_min_f32 %0, %1, %2" : "=v"(zlim) : "v"(tz.y), "v"(tlim));
+    const float tf = fminf(fminf(tx.y, ty.y), zlim);
     *tnear = tn;
     return tn <= tf;
 }
@@ -326,10 +345,13 @@ __device__ __forceinline__ uint32_t frame_row(const DevFrame& f, uint32_t r) {
 // Traversal stacks, [entry][lane]: sized at launch for the tree at hand (its depth plus the sentinel entry).
 extern __shared__ uint32_t s_stack[];
 
-template <bool COUNT>
+// FOLD_LDS: the {local colour, material} records of the reflection levels live in LDS behind the stacks
+// ([level][lane], 16 bytes each) instead of in the global `fold` array ([level][pixel]).
+template <bool COUNT, bool FOLD_LDS>
 __global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, DevFrame f, uint32_t* __restrict__ out, float4* __restrict__ fold,
-                                                    unsigned long long* __restrict__ counters) {
+                                                    unsigned long long* __restrict__ counters, uint32_t stack_entries) {
     const uint32_t lane = threadIdx.x;
+    float4* const fold_lds = (float4*)(s_stack + stack_entries * 64u) + lane;
     // Which 8x8 pixel tile this wavefront renders.  Workgroups are dealt round-robin over the 8
     // XCDs, each with an L2 of its own: in row-major order every XCD would touch every part of
     // the scene.  For big frames the blocks of one XCD instead sweep a square region of tiles at a
@@ -426,7 +448,8 @@ __global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, D
             V3 local = vadd(acc, ambient);                                                       // raytracer.rs:181
             bool reflective = specular_color.x > 0.0f || specular_color.y > 0.0f || specular_color.z > 0.0f;
             if (!(reflective && depth + 1u < f.maxdepth)) { cur = local; break; }                // raytracer.rs:187
-            fold[(size_t)depth * npix + pix] = make_float4(local.x, local.y, local.z, __uint_as_float(mat));
+            if (FOLD_LDS) fold_lds[depth * 64u] = make_float4(local.x, local.y, local.z, __uint_as_float(mat));
+            else fold[(size_t)depth * npix + pix] = make_float4(local.x, local.y, local.z, __uint_as_float(mat));
             float k2 = 2.0f * vdot(d, normal);                                                   // raytracer.rs:188-190
             d = vsub(d, vscale(normal, k2));
             o = shadow_origin;
@@ -436,7 +459,7 @@ __global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, D
         // Backward fold: final_k = local_k + specular_k (*) final_{k+1}                           raytracer.rs:194-195
         while (depth > 0) {
             depth--;
-            const float4 rec = fold[(size_t)depth * npix + pix];
+            const float4 rec = FOLD_LDS ? fold_lds[depth * 64u] : fold[(size_t)depth * npix + pix];
             const float4 m1 = sc.mats[2 * (size_t)__float_as_uint(rec.w) + 1];
             cur = vadd(v3(rec), vcmul(v3(m1), cur));
         }
@@ -499,12 +522,20 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     }
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((uint32_t)blocks), block(64);
-    // One stack entry per tree level plus the sentinel; 8 KiB (32 entries) still lets 5 wavefronts per SIMD fit.
-    const uint32_t entries = (uint32_t)(stack_depth < 7 ? 8 : stack_depth + 1);
+    // One stack entry per tree level plus the sentinel.
+    const uint32_t entries = rtk_stack_entries(stack_depth);
     if (entries > 64) return hipErrorInvalidValue;
-    const size_t lds_bytes = (size_t)entries * 64 * sizeof(uint32_t);
-    if (count) hipLaunchKernelGGL((render_kernel<true>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters);
-    else hipLaunchKernelGGL((render_kernel<false>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters);
+    size_t lds_bytes = (size_t)entries * 64 * sizeof(uint32_t);
+    const bool fold_lds = rtk_fold_in_lds(stack_depth, f->maxdepth);
+    if (fold_lds) lds_bytes += (size_t)(f->maxdepth - 1u) * 64 * sizeof(float4);
+    else if (f->maxdepth > 1 && !d_fold) return hipErrorInvalidValue;
+    if (count) {
+        if (fold_lds) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries);
+        else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries);
+    } else {
+        if (fold_lds) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries);
+        else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries);
+    }
     return hipGetLastError();
 }
 

@@ -89,7 +89,10 @@ void point_at_blob(void* d_blob, const rtl::BlobHeader& h) {
     g.dsc.mats = (const float4*)(base + h.off_materials);
     g.dsc.lights = (const float4*)(base + h.off_lights);
     g.dsc.n_list = h.n_list_shapes; g.dsc.n_lights = h.n_lights; g.dsc.root_ref = h.root_ref; g.dsc.finite_shading = h.finite_shading;
-    for (int k = 0; k < 3; k++) { g.dsc.grid_origin[k] = h.grid_origin[k]; g.dsc.grid_scale[k] = h.grid_scale[k]; }
+    for (int k = 0; k < 3; k++) {
+        g.dsc.grid_origin[k] = h.grid_origin[k]; g.dsc.grid_scale[k] = h.grid_scale[k];
+        g.dsc.inv_limit[k] = std::fmin(1e30f, 1e33f / std::fmax(h.grid_scale[k], 1e-30f));
+    }
     g.info.node_pairs = h.n_pairs; g.info.leaves = h.n_leaves; g.info.max_depth = h.max_depth; g.info.max_leaf = h.max_leaf;
     g.info.bvh_prims = h.n_tree_shapes; g.info.list_prims = h.n_list_shapes; g.info.sah_cost = h.sah_cost;
     g.have_scene = true;
@@ -103,9 +106,12 @@ int check_frame(const rt_frame* f) {
     return 0;
 }
 
-int ensure_fold(size_t records) {
+// Global array for the records of the reflection levels, for frames whose records do not fit in LDS.
+int ensure_fold(size_t npix, size_t levels) {
+    const size_t limit = (200ull << 30) / sizeof(float4);
+    if (levels != 0 && npix > limit / levels) return fail("maxdepth x pixels needs more than 200 GiB of fold records");
+    const size_t records = npix * levels;
     if (records <= cur().fold_cap) return 0;
-    if (records * sizeof(float4) > (200ull << 30)) return fail("maxdepth x pixels needs more than 200 GiB of fold records");
     if (cur().d_fold) { (void)hipFree(cur().d_fold); cur().d_fold = nullptr; cur().fold_cap = 0; }
     HIP_TRY(hipMalloc((void**)&cur().d_fold, records * sizeof(float4)));
     cur().fold_cap = records;
@@ -172,7 +178,7 @@ int render_shard(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32
     if (!d_out) return fail("output buffer is NULL");
     size_t npix = (size_t)local_rows * frame->width;
     uint32_t levels = frame->maxdepth > 1 ? frame->maxdepth - 1 : 0;
-    if (ensure_fold(npix * (size_t)levels)) return 1;
+    if (!rtk_fold_in_lds((int)g.hdr.max_depth, frame->maxdepth) && ensure_fold(npix, levels)) return 1;
     if (count_work) HIP_TRY(hipMemsetAsync(cur().d_counters, 0, 8 * sizeof(unsigned long long), cur().stream));
     if (plan_regions(*frame, &f)) return 1;
     if (stats) HIP_TRY(hipEventRecord(cur().ev0, cur().stream));

@@ -310,7 +310,7 @@ bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info
                                 h.off_lights + (size_t)s.nlights * sizeof(rtl::LightRec)};
         for (size_t e : ends) std::memset(blob->data() + e, 0, align256(e) - e);
     }
-    // Quantise the (already padded) builder boxes outwards onto the 16-bit scene grid.
+    // Quantise the (already padded) builder boxes outwards onto the 15-bit scene grid.
     {
         // The two children of the root bound everything below them.
         double glo[3] = {0, 0, 0}, ghi[3] = {0, 0, 0};
@@ -339,7 +339,7 @@ bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info
                     if (ql < 0) ql = 0;
                     if (qh > rtl::GRID_STEPS) qh = rtl::GRID_STEPS;
                     if (o + ql * sc > (double)b.lo[k] || o + qh * sc < (double)b.hi[k]) ok = false;
-                    qp[i].c[c].lo[k] = (uint16_t)ql; qp[i].c[c].hi[k] = (uint16_t)qh;
+                    qp[i].c[c].q[k][0] = (uint16_t)ql; qp[i].c[c].q[k][1] = (uint16_t)qh;
                 }
                 qp[i].c[c].ref = b.ref;
             }

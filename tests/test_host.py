@@ -336,7 +336,7 @@ HDR = struct.Struct("<IIQ5Q5II3IfI3f3f")
 def _read_blob(blob):
     (magic, ver, total, o_nodes, o_tree, o_list, o_mat, o_light, n_pairs, n_tree, n_list, n_mat, n_light, root,
      max_depth, max_leaf, n_leaves, sah, finite, gx, gy, gz, sx, sy, sz) = HDR.unpack_from(blob.tobytes()[:HDR.size])
-    assert magic == 0x52544231 and ver == 2 and total == len(blob)
+    assert magic == 0x52544231 and ver == 3 and total == len(blob)
     nodes = blob[o_nodes:o_nodes + 32 * n_pairs].view(np.uint32).reshape(n_pairs, 8)
     tree = blob[o_tree:o_tree + 48 * n_tree].view(np.uint32).reshape(n_tree, 12)
     lst = blob[o_list:o_list + 48 * n_list].view(np.uint32).reshape(n_list, 12)
@@ -349,10 +349,11 @@ def _check_tree(b):
     tf = tree.view(np.float32)
 
     def child_box(ref, c):
-        # 16-bit grid coordinates -> the exact planes they stand for (float64: exact for these products)
+        # 15-bit grid coordinates (low | high << 16 per axis) -> the exact planes they stand for (float64: exact for these products)
         w = nodes[ref, 4 * c:4 * c + 3]
-        q = np.float64([w[0] & 0xFFFF, w[0] >> 16, w[1] & 0xFFFF, w[1] >> 16, w[2] & 0xFFFF, w[2] >> 16])
-        return b["origin"] + q[:3] * b["scale"], b["origin"] + q[3:] * b["scale"]
+        lo, hi = np.float64(w & 0xFFFF), np.float64(w >> 16)
+        assert (hi < 32768).all() and (lo <= hi).all()
+        return b["origin"] + lo * b["scale"], b["origin"] + hi * b["scale"]
     seen = np.zeros(len(tree), dtype=np.int32)
     max_depth = 0
     leaves = 0
