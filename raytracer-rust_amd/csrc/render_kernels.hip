@@ -26,6 +26,10 @@
 //   sphere / plane / triangle     src/raytracer/config/shape.rs:72-96, 112-132, 149-191
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef RT_DIAG_LDS_PAD
+#include <algorithm>
+#include <cstdlib>
+#endif
 
 #include "device_types.h"
 #include "layout.h"
@@ -65,6 +69,16 @@ __device__ __forceinline__ V3 vcross(V3 a, V3 b) {
 }
 __device__ __forceinline__ float vnorm(V3 a) { return sqrtf(vdot(a, a)); }
 __device__ __forceinline__ V3 vnormalize(V3 a) { float inv = 1.0f / vnorm(a); return vscale(a, inv); }
+
+// Loads whose address is the same in every lane (the always-tested shapes, the lights) go through the scalar
+// data cache: read through the constant address space the compiler issues s_load for them, which keeps them
+// out of the vector memory path that the per-lane node and shape loads need.  The scene is never written by a kernel.
+typedef float RawF4 __attribute__((ext_vector_type(4)));
+typedef const RawF4 __attribute__((address_space(4)))* UniformF4;
+__device__ __forceinline__ float4 uniform_load(const float4* base, uint32_t index) {
+    const RawF4 v = ((UniformF4)(uintptr_t)base)[index];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 struct Counters { uint32_t nodes, prims, shadow, secondary, wave_node_iters, wave_prim_iters; };
 
@@ -215,7 +229,7 @@ template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint32_t* stack, Best* best, Counters* cnt) {
     best->t = INF; best->prim = NO_PRIM; best->order = 0xFFFFFFFFu;
     for (uint32_t i = 0; i < sc.n_list; i++) {
-        const float4 q0 = sc.list[3 * i], q1 = sc.list[3 * i + 1], q2 = sc.list[3 * i + 2];
+        const float4 q0 = uniform_load(sc.list, 3 * i), q1 = uniform_load(sc.list, 3 * i + 1), q2 = uniform_load(sc.list, 3 * i + 2);
         float t;
         if (COUNT) cnt->prims++;
         if (test_shape(q0, q1, q2, o, d, &t)) consider(best, t, LIST_FLAG | i, __float_as_uint(q1.w));
@@ -293,7 +307,7 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
                                           Counters* cnt) {
     for (uint32_t i = 0; i < sc.n_list; i++) {
         if (COUNT) cnt->prims++;
-        if (occludes(sc.list[3 * i], sc.list[3 * i + 1], sc.list[3 * i + 2], o, d, hit_back, point_light, light_dist)) return true;
+        if (occludes(uniform_load(sc.list, 3 * i), uniform_load(sc.list, 3 * i + 1), uniform_load(sc.list, 3 * i + 2), o, d, hit_back, point_light, light_dist)) return true;
     }
     uint32_t cur = sc.root_ref;
     if (cur == REF_EMPTY) return false;
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, D
             V3 acc = v3(0.0f, 0.0f, 0.0f);
             const V3 shadow_origin = vadd(point, vscale(normal, 1e-6f));                        // raytracer.rs:133
             for (uint32_t li = 0; li < sc.n_lights; li++) {                                      // raytracer.rs:126-179
-                const float4 l0 = sc.lights[2 * li], l1 = sc.lights[2 * li + 1];
+                const float4 l0 = uniform_load(sc.lights, 2 * li), l1 = uniform_load(sc.lights, 2 * li + 1);
                 const bool point_light = l0.w == 0.0f;
                 V3 light_dir; float light_dist = 0.0f;
                 if (point_light) {
@@ -529,6 +543,9 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     const bool fold_lds = rtk_fold_in_lds(stack_depth, f->maxdepth);
     if (fold_lds) lds_bytes += (size_t)(f->maxdepth - 1u) * 64 * sizeof(float4);
     else if (f->maxdepth > 1 && !d_fold) return hipErrorInvalidValue;
+#ifdef RT_DIAG_LDS_PAD
+    { static const char* pad = getenv("RT_DIAG_LDS_PAD"); if (pad) lds_bytes = std::max(lds_bytes, (size_t)atoi(pad)); }   // occupancy experiments (scripts/ab_occ.sh)
+#endif
     if (count) {
         if (fold_lds) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries);
         else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries);
