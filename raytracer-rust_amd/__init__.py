@@ -366,10 +366,22 @@ def shutdown():
 
 BUILD_ON_GPU = 1
 
+# The library keeps ONE scene resident.  Every upload takes a new token; a RayTracer whose
+# token is no longer the current one makes its own scene resident again before it renders (the reference's RayTracer
+# owns its Config and Bvh, so holding several at once is valid there).
+_resident_token = 0
+
+
+def _new_resident_token():
+    global _resident_token
+    _resident_token += 1
+    return _resident_token
+
 
 def upload_scene(scene, gpu_build=False):
     """RayTracer::new: tree build (split search on the host, or on the GPU with gpu_build=True) + upload."""
     _check(lib().rt_upload_scene_ex(C.byref(scene), BUILD_ON_GPU if gpu_build else 0))
+    _new_resident_token()
     info = rt_bvh_info()
     _check(lib().rt_get_bvh_info(C.byref(info)))
     return info.as_dict()
@@ -387,6 +399,7 @@ def copy_scene_blob(device_dst, nbytes):
 
 def adopt_scene_blob(device_ptr, nbytes):
     _check(lib().rt_adopt_scene_blob(C.c_void_p(device_ptr), nbytes))
+    _new_resident_token()
 
 
 def upload_scene_blob(blob):
@@ -397,6 +410,7 @@ def upload_scene_blob(blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         ptr, n = blob.ctypes.data, blob.size
     _check(lib().rt_upload_scene_blob(C.c_void_p(ptr), n))
+    _new_resident_token()
     info = rt_bvh_info()
     _check(lib().rt_get_bvh_info(C.byref(info)))
     return info.as_dict()
@@ -508,7 +522,6 @@ def stream():
 
 GPU_BUILD_FROM = 200_000      # shapes from which from_scene_file builds the tree on the GPU unless told otherwise
 
-
 class RayTracer:
     """RayTracer of raytracer.rs:16-83 on one MI355X."""
 
@@ -517,7 +530,9 @@ class RayTracer:
             init(0 if device is None else device)
         self.config = config
         self._scene = config.scene() if isinstance(config, Config) else config.c
+        self._gpu_build, self._cache_path = gpu_build, None
         self.bvh_info = upload_scene(self._scene, gpu_build=gpu_build)          # RayTracer::new builds the tree (raytracer.rs:32)
+        self._token = _resident_token
         self.last_stats = None
 
     @classmethod
@@ -536,6 +551,7 @@ class RayTracer:
         cache_path = cache_path or (os.fspath(path) + ".rtcache")
         self = cls.__new__(cls)
         self.last_stats = None
+        self._cache_path, self._gpu_build = cache_path, False
         try:
             cache = SceneCache(cache_path)
         except RtError:
@@ -544,6 +560,7 @@ class RayTracer:
             self.config = cache.config()
             self._scene = None
             self.bvh_info = upload_scene_blob(cache)
+            self._token = _resident_token
             self.from_cache = True
             cache.close()
             return self
@@ -553,12 +570,29 @@ class RayTracer:
         self._scene = self.config.scene()
         if gpu_build is None:
             gpu_build = self._scene.ntri + self._scene.nsph >= GPU_BUILD_FROM
+        self._gpu_build = gpu_build
         self.bvh_info = upload_scene(self._scene, gpu_build=gpu_build)
+        self._token = _resident_token
         SceneCache.write(cache_path, self.config, download_scene_blob(), source_path=path)
         self.from_cache = False
         return self
 
+    def _make_resident(self):
+        """Uploads this tracer's scene again if another RayTracer has replaced it since."""
+        if self._token == _resident_token:
+            return
+        if self._scene is not None:
+            upload_scene(self._scene, gpu_build=self._gpu_build)
+        else:
+            cache = SceneCache(self._cache_path)
+            try:
+                upload_scene_blob(cache)
+            finally:
+                cache.close()
+        self._token = _resident_token
+
     def render(self, count_work=False):
+        self._make_resident()
         pixels, self.last_stats = render(self.config.frame(), count_work=count_work)
         return Image(pixels.shape[1], pixels.shape[0], pixels)
 

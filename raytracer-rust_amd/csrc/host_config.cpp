@@ -539,9 +539,10 @@ struct CacheHeader {
     float cam_pos[3], cam_look[3], cam_up[3], cam_fov, ambient[3];
     uint32_t ntri, nsph, npl, nlights;
     char output_file[1024];
+    uint64_t header_hash;          // of the whole header block with this field zero: damage to the Config fields is noticed too
 };
 constexpr size_t CACHE_HEADER_BYTES = 4096;
-constexpr uint32_t CACHE_VERSION = 1;
+constexpr uint32_t CACHE_VERSION = 2;
 const char CACHE_MAGIC[8] = {'R', 'T', 'S', 'C', 'A', 'C', 'H', 'E'};
 static_assert(sizeof(CacheHeader) <= CACHE_HEADER_BYTES, "cache header must fit its block");
 
@@ -599,6 +600,8 @@ int rth_scene_cache_write(const char* path, const rth_config* c, const void* blo
     h.nlights = (uint32_t)(c->lights.size() / 7);
     std::memcpy(h.output_file, c->output_file.data(), c->output_file.size());
     std::memcpy(block.data(), &h, sizeof(h));
+    h.header_hash = hash64(block.data(), block.size());
+    std::memcpy(block.data(), &h, sizeof(h));
     // Written under a temporary name and renamed, so that a reader never sees half a file.
     std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
     int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -628,6 +631,12 @@ rth_scene_cache* rth_scene_cache_open(const char* path) {
     else if (h.blob_bytes != (uint64_t)st.st_size - CACHE_HEADER_BYTES) why = "scene cache: truncated";
     else if (std::memchr(h.output_file, 0, sizeof(h.output_file)) == nullptr) why = "scene cache: damaged header";
     else if (hash64((const char*)map + CACHE_HEADER_BYTES, (size_t)h.blob_bytes) != h.blob_hash) why = "scene cache: checksum mismatch";
+    else {
+        std::vector<char> block((const char*)map, (const char*)map + CACHE_HEADER_BYTES);
+        CacheHeader z = h; z.header_hash = 0;
+        std::memcpy(block.data(), &z, sizeof(z));
+        if (hash64(block.data(), block.size()) != h.header_hash) why = "scene cache: damaged header";
+    }
     if (why) { munmap(map, (size_t)st.st_size); rte::set_error(why); return nullptr; }
     rth_scene_cache* out = new rth_scene_cache();
     out->map = map; out->bytes = (size_t)st.st_size;

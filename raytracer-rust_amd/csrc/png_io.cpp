@@ -157,7 +157,12 @@ int rth_load_png(const char* path, uint32_t** pixels, uint32_t* width, uint32_t*
     int channels = color == 0 ? 1 : color == 2 ? 3 : color == 3 ? 1 : color == 4 ? 2 : color == 6 ? 4 : 0;
     if (channels == 0 || !(depth == 8 || (depth == 16 && color != 3))) return fail("PNG: unsupported colour type or bit depth");
     const size_t bpp = (size_t)channels * (depth / 8), stride = bpp * w;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    // A deflate stream expands at most 1032 times: a header that promises more than the data can hold is damaged
+    // (and must not size an allocation).
+    const uint64_t raw_bytes = ((uint64_t)stride + 1) * (uint64_t)h;
+    if (raw_bytes > (uint64_t)idat.size() * 1032u + 64u || raw_bytes > 0xFFFFFFFFull) return fail("PNG: image data does not match the header");
+    std::vector<uint8_t> raw;
+    try { raw.resize((size_t)raw_bytes); } catch (const std::exception&) { return fail("PNG: out of memory"); }
     {
         z_stream zs{};
         if (inflateInit(&zs) != Z_OK) return fail("PNG: inflate failed");

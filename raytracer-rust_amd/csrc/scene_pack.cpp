@@ -56,7 +56,8 @@ void fill_record(const rt_scene& s, const Flat& f, rtl::ShapeRec* r) {
 bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err) {
     if (h.magic != rtl::BLOB_MAGIC || h.version != rtl::BLOB_VERSION) { *err = "scene blob: bad magic or version"; return false; }
     if (h.total_bytes != bytes) { *err = "scene blob: size does not match its header"; return false; }
-    auto fits = [&](uint64_t off, uint64_t n, uint64_t each) { return off % 16 == 0 && off >= sizeof(rtl::BlobHeader) && off + n * each <= bytes; };
+    // (no sum or product that could wrap: offsets and counts come from the file)
+    auto fits = [&](uint64_t off, uint64_t n, uint64_t each) { return off % 16 == 0 && off >= sizeof(rtl::BlobHeader) && off <= bytes && n <= (bytes - off) / each; };
     if (!fits(h.off_nodes, h.n_pairs, sizeof(rtl::QuantPair)) || !fits(h.off_tree_shapes, h.n_tree_shapes, sizeof(rtl::ShapeRec)) ||
         !fits(h.off_list_shapes, h.n_list_shapes, sizeof(rtl::ShapeRec)) || !fits(h.off_materials, h.n_materials, sizeof(rtl::MaterialRec)) ||
         !fits(h.off_lights, h.n_lights, sizeof(rtl::LightRec))) {
@@ -110,6 +111,8 @@ bool validate_blob(const uint8_t* blob, size_t bytes, std::string* err) {
         seen[idx] = 1; reached++;
         if (depth > h.max_depth || depth > TREE_DEPTH_LIMIT) { *err = "scene blob: tree deeper than its header says"; return false; }
         for (int c = 0; c < 2; c++) {
+            for (int k = 0; k < 3; k++)
+                if (pairs[idx].c[c].q[k][0] > 32767u || pairs[idx].c[c].q[k][1] > 32767u) { *err = "scene blob: node box off the 15-bit grid"; return false; }
             uint32_t ref = pairs[idx].c[c].ref;
             if (ref == rtl::REF_EMPTY) continue;
             if (ref & rtl::REF_LEAF) {

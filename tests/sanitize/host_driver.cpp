@@ -57,6 +57,16 @@ static void scene_round(const std::string& path, const std::string& scratch) {
         checks++;
     }
     for (size_t cut : {(size_t)0, (size_t)17, (size_t)255, (size_t)256, bytes / 2, bytes - 1}) { (void)rth_validate_blob(copy.data(), cut); checks++; }
+    // section offsets close to 2^64: offset + count * size wraps round to a small number, the check must not
+    for (size_t field = 16; field <= 48; field += 8)
+        for (uint64_t off : std::initializer_list<uint64_t>{0xFFFFFFFFFFFFFF00ull, 0xFFFFFFFFFFFFFFF0ull, 0x8000000000000000ull, (uint64_t)bytes, (uint64_t)bytes + 16}) {
+            std::vector<uint8_t> bad = copy;
+            std::memcpy(bad.data() + field, &off, 8);
+            const bool in_place = off == (uint64_t)bytes;              // an empty section may end exactly at the end
+            const int rc = rth_validate_blob(bad.data(), bad.size());
+            REQUIRE(rc != 0 || in_place);
+            checks++;
+        }
     // scene cache: write, map, read back, and a damaged / truncated file
     const std::string cache = scratch + "/scene.rtcache";
     REQUIRE(rth_scene_cache_write(cache.c_str(), c, blob, bytes, path.c_str()) == 0);

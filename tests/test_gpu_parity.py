@@ -156,7 +156,95 @@ def test_ragged_frame_sizes(size):
     img = rt.RayTracer.new(cfg).render()
     want, _ = O.OracleScene.load(path).render(width=size[0], height=size[1])
     assert img.pixels().shape == want.shape
-    _assert_parity(img.pixels(), want, min_identical=0.99)
+    # tp64's frame is identical to the oracle's at its own size; so it must be at every other (a single pixel may sit on a
+    # powf rounding, which is the one case where a channel may differ by one)
+    if size == (1, 1):
+        _assert_parity(img.pixels(), want, min_identical=0.0)
+    else:
+        assert np.array_equal(img.pixels(), want)
+
+
+def _render_both(text, gpu_build=False):
+    cfg = rt.ParsedConfigState().parse_text(text)
+    img = rt.RayTracer(cfg, gpu_build=gpu_build).render()
+    want, _ = O.OracleScene.parse(text).render(mode=O.OracleScene.MODE_ALL)
+    return img.pixels(), want
+
+
+def test_ray_starting_inside_a_sphere_sees_nothing_of_it():
+    """shape.rs:80-83: only the near root counts, and a negative one is no hit: from inside a sphere the sphere is
+    invisible, so the frame is black (no ambient on a miss, raytracer.rs:199-201) although the camera is enclosed."""
+    text = "size 40 30\ncamera 0 0 0 0 0 -1 0 1 0 60\nambient .3 .3 .3\ndiffuse .5 .5 .5\nsphere 0 0 0 5\npoint 0 0 0 .5 .5 .5\n"
+    got, want = _render_both(text)
+    assert np.array_equal(got, want) and (got == 0xFF000000).all()
+    # a second sphere outside the first one is seen through it, lit by a light that sits inside the first sphere:
+    # the enclosing sphere does not shadow it either (its near root lies behind the shadow ray's origin)
+    text += "sphere 0 0 -9 1\n"
+    got, want = _render_both(text)
+    assert np.array_equal(got, want) and (got != 0xFF000000).any()
+
+
+def test_rays_nearly_parallel_to_a_plane_miss_it():
+    """shape.rs:113: |normal . direction| < 1e-6 is a miss, whatever the distance would be.  The camera looks along a
+    plane from a hair above it; the rays of the middle row of an odd-height frame have direction.y == 0, so normal .
+    direction is the plane's tilt: tilted by 5e-7 the row sees nothing although its rays would reach the plane at
+    t = 2000, tilted by 2e-6 it sees the plane, tilted away it misses because t < 0."""
+    middle = {}
+    for tilt in ("0", "5e-7", "-5e-7", "2e-6", "-2e-6"):
+        text = (f"size 64 47\ncamera 0 1e-3 0 0 1e-3 -1 0 1 0 1\nambient .2 .1 .1\ndiffuse .5 .6 .7\n"
+                f"plane 0 0 0 0 1 {tilt}\npoint 0 5 0 .4 .4 .4\n")
+        got, want = _render_both(text)
+        assert np.array_equal(got, want), tilt
+        assert (got[22] == 0xFF000000).all() and (got[24] != 0xFF000000).all(), tilt      # above: t < 0; below: a hit
+        middle[tilt] = int((got[23] != 0xFF000000).sum())
+    assert middle == {"0": 0, "5e-7": 0, "-5e-7": 0, "2e-6": 64, "-2e-6": 0}
+
+
+@pytest.mark.parametrize("gpu_build", [False, True])
+def test_coincident_shapes_tie_on_distance_goes_to_the_first_in_the_file(gpu_build):
+    """raytracer.rs:116-120 keeps the first of equal minima in candidate order; the candidate order of the bvh crate is
+    not part of the reference tree, so this build (and its oracle) let the shape that comes first in the scene file win.
+    Pins GPU and oracle to each other on exact ties, with and without a tree, for both tree builders."""
+    rng = np.random.default_rng(5)
+    head = ["size 96 64", "camera 0 0 9 0 0 0 0 1 0 50", "ambient .1 .1 .1", "maxdepth 2", "point 3 5 9 .7 .7 .7", "maxverts 400"]
+    tris = []
+    for i in range(40):
+        c = rng.uniform(-3, 3, 3)
+        tris.append([c + rng.uniform(-1.5, 1.5, 3) for _ in range(3)])
+    for t in tris + tris:                               # every triangle twice, same vertices
+        for v in t:
+            head.append(f"vertex {v[0]:.5f} {v[1]:.5f} {v[2]:.5f}")
+
+    def scene(copies):
+        lines = list(head)
+        for rep, (dif, spec) in enumerate(((".9 .1 .1", "0 0 0"), (".1 .9 .1", ".5 .5 .5"))[:copies]):
+            lines += [f"diffuse {dif}", f"specular {spec}", "shininess 10"]
+            for i in range(40):
+                base = 3 * (rep * 40 + i)
+                lines.append(f"tri {base} {base + 1} {base + 2}")
+        for dif in (".2 .2 .8", ".8 .8 .2")[:copies]:                                      # and a sphere twice
+            lines += [f"diffuse {dif}", "specular 0 0 0", "sphere 0 0 -2 1.5"]
+        return "\n".join(lines) + "\n"
+
+    got, want = _render_both(scene(2), gpu_build=gpu_build)
+    c = _assert_parity(got, want)
+    assert c["identical_frac"] >= 0.9999, c
+    # The copies that come second in the file never win a tie and occlude exactly what the first ones occlude, so the frame
+    # is the frame of the scene without them (the first copies do not reflect, so nothing ever looks at a second copy).
+    alone, _ = _render_both(scene(1), gpu_build=gpu_build)
+    assert np.array_equal(got, alone)
+
+
+def test_two_tracers_each_render_their_own_scene():
+    """The reference's RayTracer owns its Config and Bvh (raytracer.rs:16-38); the library holds one resident scene,
+    so a tracer whose scene was replaced by a later one makes it resident again before it renders."""
+    a_path = os.path.join(GOLDEN, "test_file", "jalon5", "tp55.test")
+    b_path = os.path.join(GOLDEN, "test_file", "jalon6", "tp63.test")
+    a = rt.RayTracer.new(rt.ParsedConfigState().load_config_file(a_path))
+    b = rt.RayTracer.new(rt.ParsedConfigState().load_config_file(b_path))
+    for tracer, path in ((a, a_path), (b, b_path), (a, a_path)):
+        diff, _ = rt.Image.compare(tracer.render(), rt.file_to_image(path[:-5] + ".png"))
+        assert diff == 0, path
 
 
 def test_render_is_deterministic_and_instrumentation_does_not_change_pixels():
@@ -272,11 +360,14 @@ def test_device_compare_equals_image_compare(size):
     import torch
     w, h = size
     a, b, ta, tb = _frames_on_device(np.random.default_rng(w * 31 + h), w, h)
-    want_count, want_diff = rt.Image.compare(rt.Image(w, h, a), rt.Image(w, h, b))      # host twin of mod.rs:54-89
+    stats, oracle_diff = O.compare(a, b)                                                # the oracle's restatement of mod.rs:54-89
+    want_count = stats["ref_diff"]
     td = torch.full((h, w), -1, dtype=torch.int32, device="cuda:0")
     got = rt.compare_frames(ta.data_ptr(), (w, h), tb.data_ptr(), (w, h), td.data_ptr())
     assert got == want_count
-    assert np.array_equal(td.cpu().numpy().view(np.uint32).reshape(-1), want_diff.data)
+    assert np.array_equal(td.cpu().numpy().view(np.uint32), oracle_diff)
+    host_count, host_diff = rt.Image.compare(rt.Image(w, h, a), rt.Image(w, h, b))      # and the library's host twin says the same
+    assert host_count == want_count and np.array_equal(host_diff.pixels(), oracle_diff)
     assert rt.compare_frames(ta.data_ptr(), (w, h), tb.data_ptr(), (w, h)) == want_count     # without a difference image
     assert rt.compare_frames(ta.data_ptr(), (w, h), ta.data_ptr(), (w, h)) == 0
     with pytest.raises(rt.RtError, match="Images have different dimensions"):

@@ -414,6 +414,24 @@ def test_tree_of_dragon_is_valid():
     _check_tree(b)
 
 
+def test_section_offsets_near_2_to_64_are_refused():
+    """offset + count * size must not be computed in a way that wraps round (a crafted header would pass and the check of
+    the nodes would then read far outside the buffer)."""
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "test.scene"))
+    blob, _ = rt.pack_scene_host(cfg.scene())
+    rt.validate_blob(blob)
+    for field in (16, 24, 32, 40, 48):                                     # off_nodes .. off_lights
+        for off in (0xFFFFFFFFFFFFFF00, 0xFFFFFFFFFFFFFFF0, 0x8000000000000000, len(blob) + 16):
+            bad = blob.copy()
+            bad[field:field + 8] = np.frombuffer(struct.pack("<Q", off), dtype=np.uint8)
+            with pytest.raises(rt.RtError):
+                rt.validate_blob(bad)
+    bad = blob.copy()                                                      # a count so large that count * size wraps
+    bad[56:60] = np.frombuffer(struct.pack("<I", 0xFFFFFFFF), dtype=np.uint8)
+    with pytest.raises(rt.RtError):
+        rt.validate_blob(bad)
+
+
 def test_small_scenes_skip_the_tree():
     cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "test_file", "jalon6", "tp63.test"))
     blob, info = rt.pack_scene_host(cfg.scene())
