@@ -166,6 +166,17 @@ int rt_assemble_tiles(const uint32_t* d_gathered, uint32_t rows_per_shard_stride
 int rt_compare_frames(const uint32_t* d_a, uint32_t width_a, uint32_t height_a, const uint32_t* d_b, uint32_t width_b, uint32_t height_b,
                       uint32_t* d_diff, uint64_t* count);
 
+/* rt_compare_frames for callers that cannot allocate: code under HIP graph capture, serving loops and harnesses with a
+ * fixed memory budget.  No counterpart in the reference.  Same kernel, but its pixel counter lives in a static device
+ * array of the library (256 bytes per GPU, held until the process ends) instead of memory from hipMalloc, and the count
+ * is delivered to DEVICE memory: *d_count (8-byte aligned) receives it once the work enqueued on rt_stream() has run; the
+ * call itself only enqueues (a memset of the counter, the kernel, an 8-byte device-to-device copy) and calls no
+ * hipMalloc, hipFree or other allocating routine.  At most RT_NOALLOC_MAX_PIXELS pixels.  Every call on a GPU uses
+ * that GPU's one array: calls that overlap on one GPU (different lanes, other threads) race; calls on one lane do not. */
+#define RT_NOALLOC_MAX_PIXELS 2147483648ull
+int rt_compare_frames_noalloc(const uint32_t* d_a, uint32_t width_a, uint32_t height_a, const uint32_t* d_b, uint32_t width_b,
+                              uint32_t height_b, uint32_t* d_diff, uint64_t* d_count);
+
 /* The per-pixel loop of save_image (src/imgcomparator/mod.rs:156-162) on the device: 0x??RRGGBB words to
  * R,G,B byte triples (3 * width * height bytes) for a PNG encoder.  Asynchronous on rt_stream(). */
 int rt_pack_rgb(const uint32_t* d_pixels, uint32_t width, uint32_t height, uint8_t* d_rgb);

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "rt_shard_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rt_assemble_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "rt_compare_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rt_compare_frames_noalloc": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rt_pack_rgb": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "rt_select_lane": (C.c_int, [C.c_int]),
     "rt_stream": (C.c_void_p, []),
@@ -497,6 +498,12 @@ def compare_frames(ptr_a, size_a, ptr_b, size_b, diff_ptr=None):
     _check(lib().rt_compare_frames(C.c_void_p(ptr_a), size_a[0], size_a[1], C.c_void_p(ptr_b), size_b[0], size_b[1],
                                    C.c_void_p(diff_ptr) if diff_ptr else None, C.byref(count)))
     return int(count.value)
+
+
+def compare_frames_noalloc(ptr_a, size_a, ptr_b, size_b, count_ptr, diff_ptr=None):
+    """compare_frames without any allocation: the count goes to device memory at count_ptr (uint64), asynchronously on stream()."""
+    _check(lib().rt_compare_frames_noalloc(C.c_void_p(ptr_a), size_a[0], size_a[1], C.c_void_p(ptr_b), size_b[0], size_b[1],
+                                           C.c_void_p(diff_ptr) if diff_ptr else None, C.c_void_p(count_ptr)))
 
 
 def pack_rgb(pixels_ptr, width, height, rgb_ptr):

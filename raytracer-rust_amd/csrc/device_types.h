@@ -75,6 +75,10 @@ extern "C" hipError_t rtk_launch_assemble(const uint32_t* d_gathered, uint32_t s
 // image_kernels.hip; pointers must be 16-byte aligned (d_rgb: 4-byte).
 extern "C" hipError_t rtk_launch_compare(const uint32_t* d_a, const uint32_t* d_b, size_t n, uint32_t* d_diff, unsigned long long* d_count,
                                          hipStream_t stream);
+// The scratch array of the entry point that allocates nothing (image_kernels.hip): looked up once per device, at rt_init.
+extern "C" hipError_t rtk_noalloc_setup(int device);
+// rt_api.cpp: the device the library is bound to, -1 before rt_init.
+extern "C" int rti_bound_device(void);
 extern "C" hipError_t rtk_launch_pack_rgb(const uint32_t* d_pixels, size_t n, uint8_t* d_rgb, hipStream_t stream);
 
 #endif

@@ -10,8 +10,11 @@
 // written per pixel.  Threads take four pixels each with 16-byte accesses.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string>
 
+#include "../../include/rt_amd.h"
 #include "device_types.h"
+#include "errors.h"
 
 namespace {
 
@@ -101,4 +104,50 @@ extern "C" hipError_t rtk_launch_pack_rgb(const uint32_t* d_pixels, size_t n, ui
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(pack_rgb_kernel, dim3(streaming_blocks(n)), dim3(256), 0, stream, d_pixels, n, d_rgb);
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ comparison that allocates nothing
+// rt_compare_frames keeps its pixel counter in device memory the library allocated at rt_init.  Callers that must not
+// allocate (HIP graph capture, serving loops with a fixed memory budget) get the same kernel with the counter in this
+// static device array instead: 256 bytes per GPU for the life of the process, of which the kernel uses the first word.
+// In host code the array's name is only a handle; its address on each GPU comes from hipGetSymbolAddress, once per device.
+static __device__ __align__(256) unsigned long long scratch[32];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+unsigned long long* scratch_ptr[MAX_DEVICES] = {};
+}
+
+// Called by rt_init with `device` current.
+extern "C" hipError_t rtk_noalloc_setup(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (scratch_ptr[device]) return hipSuccess;
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    scratch_ptr[device] = (unsigned long long*)p;
+    return hipSuccess;
+}
+
+extern "C" int rt_compare_frames_noalloc(const uint32_t* d_a, uint32_t width_a, uint32_t height_a, const uint32_t* d_b, uint32_t width_b,
+                                         uint32_t height_b, uint32_t* d_diff, uint64_t* d_count) {
+    auto fail = [](const char* m) { rte::set_error(m); return 1; };
+    const int device = rti_bound_device();
+    if (device < 0) return fail("rt_init has not been called");
+    if (height_a != height_b || width_a != width_b) return fail("Images have different dimensions");           // mod.rs:55-57
+    if (!d_a || !d_b || !d_count) return fail("rt_compare_frames_noalloc: NULL image or counter");
+    if (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)d_diff) & 15u) return fail("rt_compare_frames_noalloc: buffers must be 16-byte aligned");
+    if ((uintptr_t)d_count & 7u) return fail("rt_compare_frames_noalloc: the counter must be 8-byte aligned");
+    const uint64_t n = (uint64_t)width_a * height_a;
+    if (n > RT_NOALLOC_MAX_PIXELS) return fail("rt_compare_frames_noalloc: more than 2^31 pixels");
+    unsigned long long* const ptr = device < MAX_DEVICES ? scratch_ptr[device] : nullptr;
+    if (!ptr) return fail("rt_compare_frames_noalloc: no scratch array on this device");
+    hipStream_t stream = (hipStream_t)rt_stream();
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMemsetAsync(ptr, 0, sizeof(unsigned long long), stream);        // the last call's count is still there
+    if (e == hipSuccess) e = rtk_launch_compare(d_a, d_b, (size_t)n, d_diff, ptr, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_count, ptr, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) { rte::set_error(std::string("rt_compare_frames_noalloc: ") + hipGetErrorString(e)); return 1; }
+    return 0;
 }

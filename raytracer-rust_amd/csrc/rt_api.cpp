@@ -208,6 +208,8 @@ extern "C" {
 
 const char* rt_last_error(void) { return rte::last_error(); }
 
+int rti_bound_device(void) { return g.inited ? g.device : -1; }
+
 int rt_init(int device) {
     if (g.inited) {
         if (g.device == device) return 0;
@@ -223,6 +225,7 @@ int rt_init(int device) {
         HIP_TRY(hipEventCreate(&l.ev1));
         HIP_TRY(hipMalloc((void**)&l.d_counters, 8 * sizeof(unsigned long long)));
     }
+    HIP_TRY(rtk_noalloc_setup(device));
     g.lane = 0;
     g.device = device; g.inited = true;
     return 0;

@@ -95,6 +95,8 @@ extern "C" {
     pub fn rt_download_scene_blob(host_dst: *mut c_void, bytes: usize) -> c_int;
     pub fn rt_compare_frames(d_a: *const u32, width_a: u32, height_a: u32, d_b: *const u32, width_b: u32, height_b: u32,
                              d_diff: *mut u32, count: *mut u64) -> c_int;
+    pub fn rt_compare_frames_noalloc(d_a: *const u32, width_a: u32, height_a: u32, d_b: *const u32, width_b: u32, height_b: u32,
+                             d_diff: *mut u32, d_count: *mut u64) -> c_int;
     pub fn rt_pack_rgb(d_pixels: *const u32, width: u32, height: u32, d_rgb: *mut u8) -> c_int;
     pub fn rt_assemble_tiles(d_gathered: *const u32, rows_per_shard_stride: u32, nshards: u32, tile_rows: u32, width: u32, height: u32,
                              d_frame: *mut u32) -> c_int;
