@@ -15,8 +15,10 @@
  *     rt_last_error() describes it (the Err(String) of the reference); nothing aborts;
  *   - calls come from one thread at a time and are blocking, like the reference's render(), except where a
  *     function says it only enqueues work on rt_stream() (rt_render_tiles without stats, rt_assemble_tiles, rt_pack_rgb);
- *   - one process drives one GPU (rt_init(device)); multi-GPU jobs run one process per GPU
- *     and shard the frame by interleaved row tiles (rt_render_tiles).
+ *   - a process drives one GPU (rt_init(device)) or the first n GPUs of its node (rt_init_multi(n)): the scene is then
+ *     replicated with one RCCL broadcast and every frame is cut into interleaved row tiles over the GPUs and gathered on
+ *     the first, all inside rt_upload_scene / rt_render, so the caller's code is the same.  Jobs of one process per GPU
+ *     shard the frame themselves (rt_render_tiles, rt_assemble_tiles).
  *   - pixels are 0xFFRRGGBB, row-major, first row on top (src/raytracer/raytracer.rs:85-91,
  *     src/imgcomparator/mod.rs:14-25).
  */
@@ -103,9 +105,20 @@ typedef struct rt_bvh_info {
     double sah_cost;
 } rt_bvh_info;
 
-/* Binds the library to HIP device `device` and creates its stream.  Replaces nothing in the
+/* Binds the library to HIP device `device` and creates its streams.  Replaces nothing in the
  * reference (it has no device); called once before RayTracer::new. */
 int rt_init(int device);
+
+/* The same for the first `ngpus` GPUs of the node (1 .. RT_MAX_GPUS), driven by this one process and thread (the caller of
+ * the reference's render() is a single-threaded main, src/main.rs:11-14): creates streams on every GPU and one RCCL
+ * communicator per GPU (ncclCommInitAll).  From then on every upload replicates the scene to all GPUs with one
+ * ncclBroadcast, and rt_render / rt_render_frame cut each frame into tiles of RT_TILE_ROWS rows, tile t to GPU t % ngpus,
+ * gather the rows on the first GPU with one grouped ncclSend / ncclRecv and restore frame order there.  Device pointers
+ * the other entry points take or return (rt_render_tiles, rt_scene_blob, rt_compare_frames, ...) refer to the first GPU. */
+#define RT_MAX_GPUS 8
+#define RT_TILE_ROWS 8
+int rt_init_multi(int ngpus);
+int rt_device_count(void);   /* GPUs the library drives; 0 before rt_init */
 
 /* RayTracer::new (raytracer.rs:29-38): builds the bounding volume hierarchy on the host
  * (the reference calls Bvh::build_par at raytracer.rs:32), lays the scene out for the GPU
@@ -143,6 +156,12 @@ int rt_download_scene_blob(void* host_dst, size_t bytes);
  * instrumented kernel also fills nodes_visited / prims_tested / shadow / secondary
  * (slower; never used for timing). */
 int rt_render(const rt_frame* frame, uint32_t* out_pixels, rt_stats* stats, int count_work);
+
+/* RayTracer::render with the frame left in device memory (of the first GPU): *d_frame points at width * height pixels in
+ * a buffer of the library that stays valid until the next frame on the same lane.  With stats == NULL the call only
+ * enqueues (on the current lane of every GPU; rt_synchronize waits for them); otherwise it waits and fills *stats
+ * (kernel_ms: the longest of the GPUs' kernels; counts: all GPUs together). */
+int rt_render_frame(const rt_frame* frame, const uint32_t** d_frame, rt_stats* stats, int count_work);
 
 /* The same loop restricted to the row tiles owned by one shard: tile t (rows
  * [t*tile_rows, (t+1)*tile_rows)) belongs to shard t % nshards.  Rows of the owned tiles are
@@ -192,8 +211,8 @@ int rt_pack_rgb(const uint32_t* d_pixels, uint32_t width, uint32_t height, uint8
 #define RT_LANES 4
 int rt_select_lane(int lane);
 
-/* The HIP stream (hipStream_t) the library launches on, for callers that order their own
- * device work or events against it. */
+/* The HIP stream (hipStream_t) of the current lane on the first GPU, for callers that order their own
+ * device work or events against it (a frame over several GPUs ends on it), and a wait for the current lane of every GPU. */
 void* rt_stream(void);
 int rt_synchronize(void);
 

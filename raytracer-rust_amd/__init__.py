@@ -76,6 +76,8 @@ class rth_config_info(C.Structure):
 _SIGNATURES = {
     "rt_frame_from_camera": (C.c_int, [_FP, _FP, _FP, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, _FP, C.POINTER(rt_frame)]),
     "rt_init": (C.c_int, [C.c_int]),
+    "rt_init_multi": (C.c_int, [C.c_int]),
+    "rt_device_count": (C.c_int, []),
     "rt_upload_scene": (C.c_int, [C.POINTER(rt_scene)]),
     "rt_upload_scene_ex": (C.c_int, [C.POINTER(rt_scene), C.c_uint32]),
     "rt_get_bvh_info": (C.c_int, [C.POINTER(rt_bvh_info)]),
@@ -85,6 +87,7 @@ _SIGNATURES = {
     "rt_upload_scene_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rt_download_scene_blob": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rt_render": (C.c_int, [C.POINTER(rt_frame), C.c_void_p, C.POINTER(rt_stats), C.c_int]),
+    "rt_render_frame": (C.c_int, [C.POINTER(rt_frame), C.POINTER(C.c_void_p), C.POINTER(rt_stats), C.c_int]),
     "rt_render_tiles": (C.c_int, [C.POINTER(rt_frame), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(rt_stats), C.c_int]),
     "rt_shard_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rt_assemble_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
@@ -133,9 +136,10 @@ def _share_hip_runtime_with_torch():
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    for name in ("libamdhip64.so", "librccl.so"):          # (RCCL likewise: one copy per process, torch's when torch is there)
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
 def lib():
@@ -358,6 +362,17 @@ def init(device=0):
     _bound_device = int(device)
 
 
+def init_multi(ngpus):
+    """Binds this process to the first `ngpus` GPUs of the node: scenes are replicated and frames sharded inside the library."""
+    global _bound_device
+    _check(lib().rt_init_multi(int(ngpus)))
+    _bound_device = 0
+
+
+def device_count():
+    return int(lib().rt_device_count())
+
+
 def shutdown():
     global _bound_device
     if _lib is not None:
@@ -478,6 +493,14 @@ def render(frame, count_work=False):
     st = rt_stats()
     _check(lib().rt_render(C.byref(frame), out.ctypes.data, C.byref(st), int(bool(count_work))))
     return out, st.as_dict()
+
+
+def render_frame(frame, want_stats=False, count_work=False):
+    """Whole frame left in device memory of the first GPU: (device pointer, stats dict or None).  Without stats the call
+    only enqueues on the current lane (synchronize() waits)."""
+    p, st = C.c_void_p(), rt_stats()
+    _check(lib().rt_render_frame(C.byref(frame), C.byref(p), C.byref(st) if (want_stats or count_work) else None, int(bool(count_work))))
+    return p.value, (st.as_dict() if (want_stats or count_work) else None)
 
 
 def render_tiles(frame, shard, nshards, device_ptr, tile_rows=TILE_ROWS, want_stats=False, count_work=False):

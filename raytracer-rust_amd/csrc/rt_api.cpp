@@ -1,11 +1,17 @@
 // rt_api.cpp -- implementation of the C ABI declared in include/rt_amd.h.
 //
-// One process drives one GPU.  The scene lives in one device blob (layout.h) between
-// rt_upload_scene / rt_adopt_scene_blob and rt_shutdown; work buffers (frame, per-depth fold
-// records, counters) grow on demand and are reused across calls, one set per lane (a stream
-// with its own buffers: launches on different lanes may overlap on the GPU).  There is no CPU fallback:
-// every entry point that needs the GPU fails with an error when HIP does.
+// One process drives one GPU (rt_init) or several GPUs of one node (rt_init_multi).  The scene lives in one device
+// blob (layout.h) per GPU between an upload and rt_shutdown; with several GPUs it is built on the first and replicated
+// with one RCCL broadcast.  Work buffers (frame, per-depth fold records, counters) grow on demand and are reused across
+// calls, one set per GPU and lane (a lane is a stream with its own buffers: launches on different lanes may overlap on
+// the GPU).  A frame on several GPUs is cut into interleaved 8-row tiles, tile t to GPU t % n; every GPU renders its
+// tiles into a compact buffer, one grouped RCCL send/receive gathers them on the first GPU, and a kernel there restores
+// frame order.  One host thread enqueues everything: nothing between the kernels, the gather and the reassembly of a
+// frame waits for the host.  There is no CPU fallback: every entry point that needs the GPU fails with an error when
+// HIP does.
 #include "../../include/rt_amd.h"
+
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -38,17 +44,29 @@ struct Lane {
     // order in which the tile regions of a launch are handed out, and what it was computed for
     uint32_t* d_region_order = nullptr; uint32_t* d_region_cost = nullptr; uint32_t region_cap = 0;
     RegionKey region_key{}; bool region_key_valid = false;
+    // frames over several GPUs: this GPU's compact rows; on the first GPU the gathered rows of all and the frame
+    uint32_t* d_rows = nullptr; size_t rows_cap = 0;
+    uint32_t* d_gathered = nullptr; size_t gathered_cap = 0;
+    uint32_t* d_frame = nullptr; size_t frame_cap = 0;
 };
 constexpr int N_LANES = RT_LANES;
 
-struct State {
-    bool inited = false;
+struct Device {
     int device = -1;
     Lane lanes[N_LANES];
-    int lane = 0;                                           // the lane the next call uses
-    void* d_blob = nullptr; size_t blob_bytes = 0; bool blob_owned = false; bool have_scene = false;
-    rtl::BlobHeader hdr{};
+    void* d_blob = nullptr; size_t blob_bytes = 0; bool blob_owned = false;
     DevScene dsc{};
+};
+
+struct State {
+    bool inited = false;
+    int ndev = 0;
+    Device devs[RT_MAX_GPUS];
+    bool have_comm = false;                                 // rt_init_multi: frames go through the sharded path, scenes are replicated
+    ncclComm_t comms[RT_MAX_GPUS] = {};
+    int lane = 0;                                           // the lane the next call uses
+    bool have_scene = false;
+    rtl::BlobHeader hdr{};
     rt_bvh_info info{};
     uint32_t* d_out = nullptr; size_t out_cap = 0;          // pixels (rt_render's frame before it is copied to the host)
     // rt_render's way to the caller's (pageable) memory: pinned staging buffer, filled piece by piece by the copy
@@ -58,45 +76,94 @@ struct State {
     uint64_t scene_generation = 0;                          // bumped whenever another scene becomes resident
 };
 State g;
-Lane& cur() { return g.lanes[g.lane]; }
+Device& first() { return g.devs[0]; }
+Lane& cur() { return g.devs[0].lanes[g.lane]; }
+Lane& cur(int d) { return g.devs[d].lanes[g.lane]; }
 
 int fail(const std::string& m) { rte::set_error(m); return 1; }
 int fail_hip(const char* what, hipError_t e) { rte::set_error(std::string(what) + ": " + hipGetErrorString(e)); return 1; }
+int fail_nccl(const char* what, ncclResult_t e) { rte::set_error(std::string(what) + ": " + ncclGetErrorString(e)); return 1; }
 
 #define HIP_TRY(expr)                                                  \
     do {                                                               \
         hipError_t e_ = (expr);                                        \
         if (e_ != hipSuccess) return fail_hip(#expr, e_);              \
     } while (0)
+#define NCCL_TRY(expr)                                                 \
+    do {                                                               \
+        ncclResult_t e_ = (expr);                                      \
+        if (e_ != ncclSuccess) return fail_nccl(#expr, e_);            \
+    } while (0)
 
-// Scene changes wait for the launches of every lane.
+int use(int d) { HIP_TRY(hipSetDevice(g.devs[d].device)); return 0; }
+
+// Scene changes wait for the launches of every lane of every GPU.
 int sync_lanes() {
-    for (Lane& l : g.lanes) if (l.stream) HIP_TRY(hipStreamSynchronize(l.stream));
+    for (int d = g.ndev - 1; d >= 0; d--) {                  // ends with the first GPU current
+        if (use(d)) return 1;
+        for (Lane& l : g.devs[d].lanes) if (l.stream) HIP_TRY(hipStreamSynchronize(l.stream));
+    }
+    return 0;
+}
+
+int grow(uint32_t** p, size_t* cap, size_t pixels) {
+    if (pixels <= *cap) return 0;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    HIP_TRY(hipMalloc((void**)p, pixels * sizeof(uint32_t)));
+    *cap = pixels;
     return 0;
 }
 
 void release_scene() {
-    if (g.d_blob && g.blob_owned) (void)hipFree(g.d_blob);
-    g.d_blob = nullptr; g.blob_bytes = 0; g.blob_owned = false; g.have_scene = false;
+    for (int d = g.ndev - 1; d >= 0; d--) {
+        Device& dev = g.devs[d];
+        (void)hipSetDevice(dev.device);
+        if (dev.d_blob && dev.blob_owned) (void)hipFree(dev.d_blob);
+        dev.d_blob = nullptr; dev.blob_bytes = 0; dev.blob_owned = false;
+    }
+    g.have_scene = false;
 }
 
-void point_at_blob(void* d_blob, const rtl::BlobHeader& h) {
-    const char* base = (const char*)d_blob;
-    g.hdr = h;
-    g.dsc.nodes = (const uint4*)(base + h.off_nodes);
-    g.dsc.tree = (const float4*)(base + h.off_tree_shapes);
-    g.dsc.list = (const float4*)(base + h.off_list_shapes);
-    g.dsc.mats = (const float4*)(base + h.off_materials);
-    g.dsc.lights = (const float4*)(base + h.off_lights);
-    g.dsc.n_list = h.n_list_shapes; g.dsc.n_lights = h.n_lights; g.dsc.root_ref = h.root_ref; g.dsc.finite_shading = h.finite_shading;
+void point_at_blob(Device& dev, const rtl::BlobHeader& h) {
+    const char* base = (const char*)dev.d_blob;
+    dev.dsc.nodes = (const uint4*)(base + h.off_nodes);
+    dev.dsc.tree = (const float4*)(base + h.off_tree_shapes);
+    dev.dsc.list = (const float4*)(base + h.off_list_shapes);
+    dev.dsc.mats = (const float4*)(base + h.off_materials);
+    dev.dsc.lights = (const float4*)(base + h.off_lights);
+    dev.dsc.n_list = h.n_list_shapes; dev.dsc.n_lights = h.n_lights; dev.dsc.root_ref = h.root_ref; dev.dsc.finite_shading = h.finite_shading;
     for (int k = 0; k < 3; k++) {
-        g.dsc.grid_origin[k] = h.grid_origin[k]; g.dsc.grid_scale[k] = h.grid_scale[k];
-        g.dsc.inv_limit[k] = std::fmin(1e30f, 1e33f / std::fmax(h.grid_scale[k], 1e-30f));
+        dev.dsc.grid_origin[k] = h.grid_origin[k]; dev.dsc.grid_scale[k] = h.grid_scale[k];
+        dev.dsc.inv_limit[k] = std::fmin(1e30f, 1e33f / std::fmax(h.grid_scale[k], 1e-30f));
+    }
+}
+
+// The blob that has just been put on the first GPU becomes the scene of every GPU the library drives: one broadcast.
+int scene_is_resident(const rtl::BlobHeader& h) {
+    g.hdr = h;
+    point_at_blob(first(), h);
+    if (g.have_comm) {
+        const size_t bytes = first().blob_bytes;
+        for (int d = 1; d < g.ndev; d++) {
+            if (use(d)) return 1;
+            HIP_TRY(hipMalloc(&g.devs[d].d_blob, bytes));
+            g.devs[d].blob_owned = true; g.devs[d].blob_bytes = bytes;
+        }
+        NCCL_TRY(ncclGroupStart());
+        for (int d = 0; d < g.ndev; d++)
+            NCCL_TRY(ncclBroadcast(first().d_blob, g.devs[d].d_blob, bytes, ncclUint8, 0, g.comms[d], cur(d).stream));
+        NCCL_TRY(ncclGroupEnd());
+        for (int d = g.ndev - 1; d >= 0; d--) {
+            if (use(d)) return 1;
+            HIP_TRY(hipStreamSynchronize(cur(d).stream));
+            if (d > 0) point_at_blob(g.devs[d], h);
+        }
     }
     g.info.node_pairs = h.n_pairs; g.info.leaves = h.n_leaves; g.info.max_depth = h.max_depth; g.info.max_leaf = h.max_leaf;
     g.info.bvh_prims = h.n_tree_shapes; g.info.list_prims = h.n_list_shapes; g.info.sah_cost = h.sah_cost;
     g.have_scene = true;
     g.scene_generation++;
+    return 0;
 }
 
 int check_frame(const rt_frame* f) {
@@ -107,14 +174,14 @@ int check_frame(const rt_frame* f) {
 }
 
 // Global array for the records of the reflection levels, for frames whose records do not fit in LDS.
-int ensure_fold(size_t npix, size_t levels) {
+int ensure_fold(Lane& lane, size_t npix, size_t levels) {
     const size_t limit = (200ull << 30) / sizeof(float4);
     if (levels != 0 && npix > limit / levels) return fail("maxdepth x pixels needs more than 200 GiB of fold records");
     const size_t records = npix * levels;
-    if (records <= cur().fold_cap) return 0;
-    if (cur().d_fold) { (void)hipFree(cur().d_fold); cur().d_fold = nullptr; cur().fold_cap = 0; }
-    HIP_TRY(hipMalloc((void**)&cur().d_fold, records * sizeof(float4)));
-    cur().fold_cap = records;
+    if (records <= lane.fold_cap) return 0;
+    if (lane.d_fold) { (void)hipFree(lane.d_fold); lane.d_fold = nullptr; lane.fold_cap = 0; }
+    HIP_TRY(hipMalloc((void**)&lane.d_fold, records * sizeof(float4)));
+    lane.fold_cap = records;
     return 0;
 }
 
@@ -126,7 +193,7 @@ int ensure_fold(size_t npix, size_t levels) {
 // one-workgroup sort behind the kernel turns that into the order in which the next launch of the same frame
 // geometry hands its regions out: slowest first, cheap ones last to fill the end.  The first launch of a
 // geometry uses raster order.  Only the order of the work changes, never a pixel.
-int plan_regions(const rt_frame& fr, DevFrame* f) {
+int plan_regions(Lane& lane, const rt_frame& fr, DevFrame* f) {
     const uint32_t tiles_x = (f->width + 7u) >> 3, tiles_y = (f->local_rows + 7u) >> 3;
     f->region_log2 = region_log2_for((uint64_t)tiles_x * tiles_y);
     f->regions_x = 0; f->n_regions = 0; f->region_order = nullptr; f->region_cost = nullptr;
@@ -138,29 +205,28 @@ int plan_regions(const rt_frame& fr, DevFrame* f) {
     RegionKey key{};
     key.width = fr.width; key.height = fr.height;
     key.shard = f->shard; key.nshards = f->nshards; key.tile_rows = f->tile_rows; key.scene = g.scene_generation;
-    if (!cur().region_key_valid || std::memcmp(&key, &cur().region_key, sizeof(key)) != 0) {
-        if (f->n_regions > cur().region_cap) {
-            if (cur().d_region_order) { (void)hipFree(cur().d_region_order); cur().d_region_order = nullptr; cur().region_cap = 0; }
-            if (cur().d_region_cost) { (void)hipFree(cur().d_region_cost); cur().d_region_cost = nullptr; }
-            HIP_TRY(hipMalloc((void**)&cur().d_region_order, (size_t)f->n_regions * sizeof(uint32_t)));
-            HIP_TRY(hipMalloc((void**)&cur().d_region_cost, (size_t)f->n_regions * sizeof(uint32_t)));
-            cur().region_cap = f->n_regions;
+    if (!lane.region_key_valid || std::memcmp(&key, &lane.region_key, sizeof(key)) != 0) {
+        if (f->n_regions > lane.region_cap) {
+            if (lane.d_region_order) { (void)hipFree(lane.d_region_order); lane.d_region_order = nullptr; lane.region_cap = 0; }
+            if (lane.d_region_cost) { (void)hipFree(lane.d_region_cost); lane.d_region_cost = nullptr; }
+            HIP_TRY(hipMalloc((void**)&lane.d_region_order, (size_t)f->n_regions * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&lane.d_region_cost, (size_t)f->n_regions * sizeof(uint32_t)));
+            lane.region_cap = f->n_regions;
         }
         // All costs equal: the sort leaves the regions in index order.
-        HIP_TRY(hipMemsetAsync(cur().d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), cur().stream));
-        HIP_TRY(rtk_launch_sort_regions(cur().d_region_cost, f->n_regions, cur().d_region_order, cur().stream));
-        cur().region_key = key; cur().region_key_valid = true;
+        HIP_TRY(hipMemsetAsync(lane.d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), lane.stream));
+        HIP_TRY(rtk_launch_sort_regions(lane.d_region_cost, f->n_regions, lane.d_region_order, lane.stream));
+        lane.region_key = key; lane.region_key_valid = true;
     }
-    HIP_TRY(hipMemsetAsync(cur().d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), cur().stream));
-    f->region_order = cur().d_region_order;
-    f->region_cost = cur().d_region_cost;
+    HIP_TRY(hipMemsetAsync(lane.d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), lane.stream));
+    f->region_order = lane.d_region_order;
+    f->region_cost = lane.d_region_cost;
     return 0;
 }
 
-// Launches the render kernel for one shard into d_out (device).  With stats != NULL the call
-// is timed with HIP events on the library's stream and waits for completion.
-int render_shard(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32_t tile_rows, uint32_t* d_out, rt_stats* stats, int count_work) {
-    auto t0 = std::chrono::steady_clock::now();
+// Enqueues the render kernel for one shard on GPU d (current lane) into d_out (memory of that GPU).  `timed`:
+// events around the kernel are recorded for collect_stats.
+int enqueue_shard(int d, const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32_t tile_rows, uint32_t* d_out, bool timed, int count_work) {
     if (!g.inited) return fail("rt_init has not been called");
     if (!g.have_scene) return fail("no scene uploaded");
     if (check_frame(frame)) return 1;
@@ -173,32 +239,127 @@ int render_shard(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32
     f.width = frame->width; f.height = frame->height; f.maxdepth = frame->maxdepth;
     std::memcpy(f.ambient, frame->ambient, sizeof(f.ambient));
     f.shard = shard; f.nshards = nshards; f.tile_rows = tile_rows; f.local_rows = local_rows;
-    if (stats) std::memset(stats, 0, sizeof(*stats));
-    if (local_rows == 0) return 0;
+    if (use(d)) return 1;
+    Lane& lane = cur(d);
+    if (local_rows == 0) {
+        if (timed) { HIP_TRY(hipEventRecord(lane.ev0, lane.stream)); HIP_TRY(hipEventRecord(lane.ev1, lane.stream)); }
+        return 0;
+    }
     if (!d_out) return fail("output buffer is NULL");
     size_t npix = (size_t)local_rows * frame->width;
     uint32_t levels = frame->maxdepth > 1 ? frame->maxdepth - 1 : 0;
-    if (!rtk_fold_in_lds((int)g.hdr.max_depth, frame->maxdepth) && ensure_fold(npix, levels)) return 1;
-    if (count_work) HIP_TRY(hipMemsetAsync(cur().d_counters, 0, 8 * sizeof(unsigned long long), cur().stream));
-    if (plan_regions(*frame, &f)) return 1;
-    if (stats) HIP_TRY(hipEventRecord(cur().ev0, cur().stream));
-    HIP_TRY(rtk_launch_render(&g.dsc, &f, d_out, cur().d_fold, cur().d_counters, (int)g.hdr.max_depth, count_work, cur().stream));
-    if (f.region_cost) HIP_TRY(rtk_launch_sort_regions(f.region_cost, f.n_regions, cur().d_region_order, cur().stream));
+    if (!rtk_fold_in_lds((int)g.hdr.max_depth, frame->maxdepth) && ensure_fold(lane, npix, levels)) return 1;
+    if (count_work) HIP_TRY(hipMemsetAsync(lane.d_counters, 0, 8 * sizeof(unsigned long long), lane.stream));
+    if (plan_regions(lane, *frame, &f)) return 1;
+    if (timed) HIP_TRY(hipEventRecord(lane.ev0, lane.stream));
+    HIP_TRY(rtk_launch_render(&g.devs[d].dsc, &f, d_out, lane.d_fold, lane.d_counters, (int)g.hdr.max_depth, count_work, lane.stream));
+    if (f.region_cost) HIP_TRY(rtk_launch_sort_regions(f.region_cost, f.n_regions, lane.d_region_order, lane.stream));
+    if (timed) HIP_TRY(hipEventRecord(lane.ev1, lane.stream));
+    return 0;
+}
+
+// Waits for the shard enqueued last on GPU d (timed) and adds its work to *stats; kernel_ms is the longest of the GPUs.
+int collect_stats(int d, const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32_t tile_rows, int count_work, rt_stats* stats) {
+    if (use(d)) return 1;
+    Lane& lane = cur(d);
+    HIP_TRY(hipEventSynchronize(lane.ev1));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, lane.ev0, lane.ev1));
+    stats->kernel_ms = std::max(stats->kernel_ms, (double)ms);
+    const uint32_t local_rows = rt_shard_rows(frame->height, shard, nshards, tile_rows);
+    stats->primary += (uint64_t)local_rows * frame->width;
+    if (count_work && local_rows) {
+        unsigned long long c[8];
+        HIP_TRY(hipMemcpy(c, lane.d_counters, sizeof(c), hipMemcpyDeviceToHost));
+        stats->nodes_visited += c[0]; stats->prims_tested += c[1]; stats->shadow += c[2]; stats->secondary += c[3];
+        stats->box_passes += c[4]; stats->shape_passes += c[5];
+    }
+    return 0;
+}
+
+// One shard on the first GPU, as rt_render_tiles and the single-GPU rt_render want it.
+int render_shard(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32_t tile_rows, uint32_t* d_out, rt_stats* stats, int count_work) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (enqueue_shard(0, frame, shard, nshards, tile_rows, d_out, stats != nullptr, count_work)) return 1;
     if (stats) {
-        HIP_TRY(hipEventRecord(cur().ev1, cur().stream));
-        HIP_TRY(hipEventSynchronize(cur().ev1));
-        float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, cur().ev0, cur().ev1));
-        stats->kernel_ms = ms;
-        stats->primary = npix;
-        if (count_work) {
-            unsigned long long c[8];
-            HIP_TRY(hipMemcpy(c, cur().d_counters, sizeof(c), hipMemcpyDeviceToHost));
-            stats->nodes_visited = c[0]; stats->prims_tested = c[1]; stats->shadow = c[2]; stats->secondary = c[3];
-            stats->box_passes = c[4]; stats->shape_passes = c[5];
-        }
+        if (collect_stats(0, frame, shard, nshards, tile_rows, count_work, stats)) return 1;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    return 0;
+}
+
+// A whole frame over every GPU the library drives; the frame ends up in the first GPU's buffer of the current
+// lane (*d_frame).  Enqueue only, unless stats are wanted.
+int render_frame_all(const rt_frame* frame, const uint32_t** d_frame, rt_stats* stats, int count_work) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (!g.inited) return fail("rt_init has not been called");
+    if (!g.have_scene) return fail("no scene uploaded");
+    if (check_frame(frame)) return 1;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    const uint32_t n = (uint32_t)g.ndev, tile_rows = RT_TILE_ROWS, W = frame->width, H = frame->height;
+    const size_t npix = (size_t)W * H;
+    if (use(0)) return 1;
+    Lane& l0 = cur(0);
+    if (grow(&l0.d_frame, &l0.frame_cap, npix)) return 1;
+    if (!g.have_comm) {                                      // one GPU, no communicator: straight into the frame
+        if (enqueue_shard(0, frame, 0, 1, tile_rows, l0.d_frame, stats != nullptr, count_work)) return 1;
+    } else {
+        const uint32_t stride = rt_shard_rows(H, 0, n, tile_rows);            // shard 0 owns the most rows
+        if (grow(&l0.d_gathered, &l0.gathered_cap, (size_t)n * stride * W)) return 1;
+        for (uint32_t d = 0; d < n; d++) {
+            uint32_t* rows = l0.d_gathered;
+            if (d > 0) {
+                if (use((int)d)) return 1;
+                if (grow(&cur((int)d).d_rows, &cur((int)d).rows_cap, (size_t)stride * W)) return 1;
+                rows = cur((int)d).d_rows;
+            }
+            if (enqueue_shard((int)d, frame, d, n, tile_rows, rows, stats != nullptr, count_work)) return 1;
+        }
+        if (n > 1) {
+            NCCL_TRY(ncclGroupStart());
+            for (uint32_t d = 1; d < n; d++) {
+                const size_t count = (size_t)rt_shard_rows(H, d, n, tile_rows) * W;
+                if (count == 0) continue;
+                NCCL_TRY(ncclSend(cur((int)d).d_rows, count, ncclUint32, 0, g.comms[d], cur((int)d).stream));
+                NCCL_TRY(ncclRecv(l0.d_gathered + (size_t)d * stride * W, count, ncclUint32, (int)d, g.comms[0], l0.stream));
+            }
+            NCCL_TRY(ncclGroupEnd());
+        }
+        if (use(0)) return 1;
+        HIP_TRY(rtk_launch_assemble(l0.d_gathered, stride, n, tile_rows, W, H, l0.d_frame, l0.stream));
+    }
+    if (stats) {
+        const uint32_t shards = g.have_comm ? n : 1u;
+        for (uint32_t d = shards; d-- > 0;) if (collect_stats((int)d, frame, d, shards, tile_rows, count_work, stats)) return 1;
+        HIP_TRY(hipStreamSynchronize(l0.stream));           // (collect_stats left the first GPU current)
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (use(0)) return 1;
+    if (d_frame) *d_frame = l0.d_frame;
+    return 0;
+}
+
+int init_devices(int first_device, int count) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (first_device < 0 || count < 1 || first_device + count > n) return fail("rt_init: no such HIP device");
+    for (int d = 0; d < count; d++) {
+        Device& dev = g.devs[d];
+        dev.device = first_device + d;
+        g.ndev = d + 1;
+        HIP_TRY(hipSetDevice(dev.device));
+        for (Lane& l : dev.lanes) {
+            HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreate(&l.ev0));
+            HIP_TRY(hipEventCreate(&l.ev1));
+            HIP_TRY(hipMalloc((void**)&l.d_counters, 8 * sizeof(unsigned long long)));
+        }
+        HIP_TRY(rtk_noalloc_setup(dev.device));
+    }
+    HIP_TRY(hipSetDevice(first().device));
+    g.lane = 0;
+    g.inited = true;
     return 0;
 }
 
@@ -208,28 +369,34 @@ extern "C" {
 
 const char* rt_last_error(void) { return rte::last_error(); }
 
-int rti_bound_device(void) { return g.inited ? g.device : -1; }
+int rti_bound_device(void) { return g.inited ? first().device : -1; }
 
 int rt_init(int device) {
     if (g.inited) {
-        if (g.device == device) return 0;
+        if (!g.have_comm && first().device == device) return 0;
         return fail("rt_init: already bound to another device; call rt_shutdown first");
     }
-    int n = 0;
-    HIP_TRY(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n) return fail("rt_init: no such HIP device");
-    HIP_TRY(hipSetDevice(device));
-    for (Lane& l : g.lanes) {
-        HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreate(&l.ev0));
-        HIP_TRY(hipEventCreate(&l.ev1));
-        HIP_TRY(hipMalloc((void**)&l.d_counters, 8 * sizeof(unsigned long long)));
-    }
-    HIP_TRY(rtk_noalloc_setup(device));
-    g.lane = 0;
-    g.device = device; g.inited = true;
+    if (init_devices(device, 1)) { const std::string m = rte::last_error(); rt_shutdown(); return fail(m); }
     return 0;
 }
+
+int rt_init_multi(int ngpus) {
+    if (g.inited) {
+        if (g.have_comm && g.ndev == ngpus) return 0;
+        return fail("rt_init_multi: already initialised differently; call rt_shutdown first");
+    }
+    if (ngpus < 1 || ngpus > RT_MAX_GPUS) return fail("rt_init_multi: between 1 and " + std::to_string(RT_MAX_GPUS) + " GPUs");
+    if (init_devices(0, ngpus)) { const std::string m = rte::last_error(); rt_shutdown(); return fail(m); }
+    int ids[RT_MAX_GPUS];
+    for (int d = 0; d < ngpus; d++) ids[d] = g.devs[d].device;
+    ncclResult_t e = ncclCommInitAll(g.comms, ngpus, ids);
+    if (e != ncclSuccess) { rt_shutdown(); return fail_nccl("ncclCommInitAll", e); }
+    g.have_comm = true;
+    HIP_TRY(hipSetDevice(first().device));
+    return 0;
+}
+
+int rt_device_count(void) { return g.inited ? g.ndev : 0; }
 
 int rt_upload_scene(const rt_scene* scene) {
     if (!g.inited) return fail("rt_init has not been called");
@@ -238,16 +405,14 @@ int rt_upload_scene(const rt_scene* scene) {
     if (!rtp::pack_scene(*scene, &blob, &info, &err)) return fail(err);
     rtl::BlobHeader h; std::memcpy(&h, blob.data(), sizeof(h));
     if (!rtp::validate_header(h, blob.size(), &err)) return fail(err);
-    HIP_TRY(hipSetDevice(g.device));
     if (sync_lanes()) return 1;
     release_scene();
-    HIP_TRY(hipMalloc(&g.d_blob, blob.size()));
-    g.blob_owned = true; g.blob_bytes = blob.size();
-    HIP_TRY(hipMemcpyAsync(g.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, cur().stream));
+    HIP_TRY(hipMalloc(&first().d_blob, blob.size()));
+    first().blob_owned = true; first().blob_bytes = blob.size();
+    HIP_TRY(hipMemcpyAsync(first().d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, cur().stream));
     HIP_TRY(hipStreamSynchronize(cur().stream));
-    point_at_blob(g.d_blob, h);
     g.info = info;
-    return 0;
+    return scene_is_resident(h);
 }
 
 int rt_upload_scene_ex(const rt_scene* scene, uint32_t flags) {
@@ -264,7 +429,6 @@ int rt_upload_scene_ex(const rt_scene* scene, uint32_t flags) {
     in.mats = parts.mats.data(); in.n_mats = (uint32_t)parts.mats.size();
     in.lights = parts.lights.data(); in.n_lights = (uint32_t)parts.lights.size();
     in.finite_shading = parts.finite_shading; in.pad_abs = parts.pad_abs; in.depth_limit = rtp::TREE_DEPTH_LIMIT;
-    HIP_TRY(hipSetDevice(g.device));
     if (sync_lanes()) return 1;
     rtg::BuiltScene built{};
     rtg::BuildStatus st = rtg::build_scene_on_gpu(in, cur().stream, &built, &err);
@@ -272,9 +436,9 @@ int rt_upload_scene_ex(const rt_scene* scene, uint32_t flags) {
     if (st != rtg::BUILD_OK) return fail(err);
     if (!rtp::validate_header(built.header, built.bytes, &err)) { (void)hipFree(built.d_blob); return fail(err); }
     release_scene();
-    g.d_blob = built.d_blob; g.blob_bytes = built.bytes; g.blob_owned = true;
+    first().d_blob = built.d_blob; first().blob_bytes = built.bytes; first().blob_owned = true;
     g.info = rt_bvh_info{};
-    point_at_blob(g.d_blob, built.header);
+    if (scene_is_resident(built.header)) return 1;
     g.info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }
@@ -284,23 +448,21 @@ int rt_upload_scene_blob(const void* host_blob, size_t bytes) {
     std::string err;
     if (!rtp::validate_blob((const uint8_t*)host_blob, bytes, &err)) return fail(err);
     rtl::BlobHeader h; std::memcpy(&h, host_blob, sizeof(h));
-    HIP_TRY(hipSetDevice(g.device));
     if (sync_lanes()) return 1;
     release_scene();
-    HIP_TRY(hipMalloc(&g.d_blob, bytes));
-    g.blob_owned = true; g.blob_bytes = bytes;
-    HIP_TRY(hipMemcpyAsync(g.d_blob, host_blob, bytes, hipMemcpyHostToDevice, cur().stream));
+    HIP_TRY(hipMalloc(&first().d_blob, bytes));
+    first().blob_owned = true; first().blob_bytes = bytes;
+    HIP_TRY(hipMemcpyAsync(first().d_blob, host_blob, bytes, hipMemcpyHostToDevice, cur().stream));
     HIP_TRY(hipStreamSynchronize(cur().stream));
     g.info = rt_bvh_info{};
-    point_at_blob(g.d_blob, h);
-    return 0;
+    return scene_is_resident(h);
 }
 
 int rt_download_scene_blob(void* host_dst, size_t bytes) {
     if (!g.have_scene) return fail("no scene uploaded");
-    if (!host_dst || bytes != g.blob_bytes) return fail("rt_download_scene_blob: destination must be exactly the blob size");
-    HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(hipMemcpyAsync(host_dst, g.d_blob, bytes, hipMemcpyDeviceToHost, cur().stream));
+    if (!host_dst || bytes != first().blob_bytes) return fail("rt_download_scene_blob: destination must be exactly the blob size");
+    if (use(0)) return 1;
+    HIP_TRY(hipMemcpyAsync(host_dst, first().d_blob, bytes, hipMemcpyDeviceToHost, cur().stream));
     HIP_TRY(hipStreamSynchronize(cur().stream));
     return 0;
 }
@@ -315,15 +477,15 @@ int rt_get_bvh_info(rt_bvh_info* out) {
 int rt_scene_blob(void** device_ptr, size_t* bytes) {
     if (!g.have_scene) return fail("no scene uploaded");
     if (!device_ptr || !bytes) return fail("rt_scene_blob: NULL argument");
-    *device_ptr = g.d_blob; *bytes = g.blob_bytes;
+    *device_ptr = first().d_blob; *bytes = first().blob_bytes;
     return 0;
 }
 
 int rt_copy_scene_blob(void* device_dst, size_t bytes) {
     if (!g.have_scene) return fail("no scene uploaded");
-    if (!device_dst || bytes != g.blob_bytes) return fail("rt_copy_scene_blob: destination must be exactly the blob size");
-    HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(hipMemcpyAsync(device_dst, g.d_blob, bytes, hipMemcpyDeviceToDevice, cur().stream));
+    if (!device_dst || bytes != first().blob_bytes) return fail("rt_copy_scene_blob: destination must be exactly the blob size");
+    if (use(0)) return 1;
+    HIP_TRY(hipMemcpyAsync(device_dst, first().d_blob, bytes, hipMemcpyDeviceToDevice, cur().stream));
     HIP_TRY(hipStreamSynchronize(cur().stream));
     return 0;
 }
@@ -331,17 +493,15 @@ int rt_copy_scene_blob(void* device_dst, size_t bytes) {
 int rt_adopt_scene_blob(void* device_ptr, size_t bytes) {
     if (!g.inited) return fail("rt_init has not been called");
     if (!device_ptr || bytes < sizeof(rtl::BlobHeader)) return fail("rt_adopt_scene_blob: buffer too small");
-    HIP_TRY(hipSetDevice(g.device));
     if (sync_lanes()) return 1;
     rtl::BlobHeader h;
     HIP_TRY(hipMemcpy(&h, device_ptr, sizeof(h), hipMemcpyDeviceToHost));
     std::string err;
     if (!rtp::validate_header(h, bytes, &err)) return fail(err);
     release_scene();
-    g.d_blob = device_ptr; g.blob_bytes = bytes; g.blob_owned = false;
-    point_at_blob(device_ptr, h);
-    g.info.build_ms = 0.0;
-    return 0;
+    first().d_blob = device_ptr; first().blob_bytes = bytes; first().blob_owned = false;
+    g.info = rt_bvh_info{};
+    return scene_is_resident(h);
 }
 
 uint32_t rt_shard_rows(uint32_t height, uint32_t shard, uint32_t nshards, uint32_t tile_rows) {
@@ -358,8 +518,11 @@ uint32_t rt_shard_rows(uint32_t height, uint32_t shard, uint32_t nshards, uint32
 
 int rt_render_tiles(const rt_frame* frame, uint32_t shard, uint32_t nshards, uint32_t tile_rows, uint32_t* d_out, rt_stats* stats,
                     int count_work) {
-    if (g.inited) HIP_TRY(hipSetDevice(g.device));
     return render_shard(frame, shard, nshards, tile_rows, d_out, stats, count_work);
+}
+
+int rt_render_frame(const rt_frame* frame, const uint32_t** d_frame, rt_stats* stats, int count_work) {
+    return render_frame_all(frame, d_frame, stats, count_work);
 }
 
 int rt_render(const rt_frame* frame, uint32_t* out_pixels, rt_stats* stats, int count_work) {
@@ -367,25 +530,27 @@ int rt_render(const rt_frame* frame, uint32_t* out_pixels, rt_stats* stats, int 
     if (!g.inited) return fail("rt_init has not been called");
     if (check_frame(frame)) return 1;
     if (!out_pixels) return fail("output buffer is NULL");
-    HIP_TRY(hipSetDevice(g.device));
+    if (use(0)) return 1;
     size_t npix = (size_t)frame->width * frame->height;
-    if (npix > g.out_cap) {
-        if (g.d_out) { (void)hipFree(g.d_out); g.d_out = nullptr; g.out_cap = 0; }
-        HIP_TRY(hipMalloc((void**)&g.d_out, npix * sizeof(uint32_t)));
-        g.out_cap = npix;
-    }
     if (npix > g.stage_cap) {
         if (g.h_stage) { (void)hipHostFree(g.h_stage); g.h_stage = nullptr; g.stage_cap = 0; }
         HIP_TRY(hipHostMalloc((void**)&g.h_stage, npix * sizeof(uint32_t), hipHostMallocDefault));
         g.stage_cap = npix;
     }
     rt_stats local{};
-    if (render_shard(frame, 0, 1, 8, g.d_out, &local, count_work)) return 1;
+    const uint32_t* d_src = nullptr;
+    if (g.have_comm) {
+        if (render_frame_all(frame, &d_src, &local, count_work)) return 1;
+    } else {
+        if (grow(&g.d_out, &g.out_cap, npix)) return 1;
+        if (render_shard(frame, 0, 1, RT_TILE_ROWS, g.d_out, &local, count_work)) return 1;
+        d_src = g.d_out;
+    }
     const size_t n_pieces = npix >= (1u << 20) ? 8 : 1, per_piece = (npix + n_pieces - 1) / n_pieces;
     for (size_t k = 0; k < n_pieces; k++) {
         const size_t a = std::min(npix, k * per_piece), b = std::min(npix, a + per_piece);
         if (!g.piece_done[k]) HIP_TRY(hipEventCreateWithFlags(&g.piece_done[k], hipEventDisableTiming));
-        if (b > a) HIP_TRY(hipMemcpyAsync(g.h_stage + a, g.d_out + a, (b - a) * sizeof(uint32_t), hipMemcpyDeviceToHost, cur().stream));
+        if (b > a) HIP_TRY(hipMemcpyAsync(g.h_stage + a, d_src + a, (b - a) * sizeof(uint32_t), hipMemcpyDeviceToHost, cur().stream));
         HIP_TRY(hipEventRecord(g.piece_done[k], cur().stream));
     }
     for (size_t k = 0; k < n_pieces; k++) {
@@ -407,7 +572,7 @@ int rt_assemble_tiles(const uint32_t* d_gathered, uint32_t rows_per_shard_stride
     if (nshards == 0 || tile_rows == 0 || width == 0 || height == 0) return fail("rt_assemble_tiles: bad geometry");
     for (uint32_t s = 0; s < nshards; s++)
         if (rt_shard_rows(height, s, nshards, tile_rows) > rows_per_shard_stride) return fail("rt_assemble_tiles: stride smaller than a shard");
-    HIP_TRY(hipSetDevice(g.device));
+    if (use(0)) return 1;
     HIP_TRY(rtk_launch_assemble(d_gathered, rows_per_shard_stride, nshards, tile_rows, width, height, d_frame, cur().stream));
     return 0;
 }
@@ -418,7 +583,7 @@ int rt_compare_frames(const uint32_t* d_a, uint32_t width_a, uint32_t height_a, 
     if (height_a != height_b || width_a != width_b) return fail("Images have different dimensions");            // mod.rs:55-57
     if (!d_a || !d_b) return fail("rt_compare_frames: NULL image");
     if (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)d_diff) & 15u) return fail("rt_compare_frames: buffers must be 16-byte aligned");
-    HIP_TRY(hipSetDevice(g.device));
+    if (use(0)) return 1;
     HIP_TRY(hipMemsetAsync(cur().d_counters, 0, sizeof(unsigned long long), cur().stream));
     HIP_TRY(rtk_launch_compare(d_a, d_b, (size_t)width_a * height_a, d_diff, cur().d_counters, cur().stream));
     unsigned long long c = 0;
@@ -432,7 +597,7 @@ int rt_pack_rgb(const uint32_t* d_pixels, uint32_t width, uint32_t height, uint8
     if (!g.inited) return fail("rt_init has not been called");
     if (!d_pixels || !d_rgb) return fail("rt_pack_rgb: NULL buffer");
     if (((uintptr_t)d_pixels & 15u) || ((uintptr_t)d_rgb & 3u)) return fail("rt_pack_rgb: pixels must be 16-byte and rgb 4-byte aligned");
-    HIP_TRY(hipSetDevice(g.device));
+    if (use(0)) return 1;
     HIP_TRY(rtk_launch_pack_rgb(d_pixels, (size_t)width * height, d_rgb, cur().stream));
     return 0;
 }
@@ -444,30 +609,40 @@ int rt_select_lane(int lane) {
     return 0;
 }
 
-void* rt_stream(void) { return (void*)cur().stream; }
+void* rt_stream(void) { return g.inited ? (void*)cur().stream : nullptr; }
 
 int rt_synchronize(void) {
     if (!g.inited) return fail("rt_init has not been called");
-    HIP_TRY(hipStreamSynchronize(cur().stream));
+    for (int d = g.ndev - 1; d >= 0; d--) {                 // the first GPU last: its stream ends a frame, and it stays current
+        if (use(d)) return 1;
+        HIP_TRY(hipStreamSynchronize(cur(d).stream));
+    }
     return 0;
 }
 
 void rt_shutdown(void) {
-    if (!g.inited) return;
-    (void)hipSetDevice(g.device);
+    if (g.ndev == 0) { g = State(); return; }
     (void)sync_lanes();
     release_scene();
+    if (g.have_comm) for (int d = 0; d < g.ndev; d++) if (g.comms[d]) (void)ncclCommDestroy(g.comms[d]);
+    (void)hipSetDevice(first().device);
     if (g.d_out) (void)hipFree(g.d_out);
     if (g.h_stage) (void)hipHostFree(g.h_stage);
     for (hipEvent_t e : g.piece_done) if (e) (void)hipEventDestroy(e);
-    for (Lane& l : g.lanes) {
-        if (l.d_fold) (void)hipFree(l.d_fold);
-        if (l.d_counters) (void)hipFree(l.d_counters);
-        if (l.d_region_order) (void)hipFree(l.d_region_order);
-        if (l.d_region_cost) (void)hipFree(l.d_region_cost);
-        if (l.ev0) (void)hipEventDestroy(l.ev0);
-        if (l.ev1) (void)hipEventDestroy(l.ev1);
-        if (l.stream) (void)hipStreamDestroy(l.stream);
+    for (int d = 0; d < g.ndev; d++) {
+        (void)hipSetDevice(g.devs[d].device);
+        for (Lane& l : g.devs[d].lanes) {
+            if (l.d_fold) (void)hipFree(l.d_fold);
+            if (l.d_counters) (void)hipFree(l.d_counters);
+            if (l.d_region_order) (void)hipFree(l.d_region_order);
+            if (l.d_region_cost) (void)hipFree(l.d_region_cost);
+            if (l.d_rows) (void)hipFree(l.d_rows);
+            if (l.d_gathered) (void)hipFree(l.d_gathered);
+            if (l.d_frame) (void)hipFree(l.d_frame);
+            if (l.ev0) (void)hipEventDestroy(l.ev0);
+            if (l.ev1) (void)hipEventDestroy(l.ev1);
+            if (l.stream) (void)hipStreamDestroy(l.stream);
+        }
     }
     g = State();
 }

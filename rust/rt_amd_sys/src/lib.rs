@@ -87,6 +87,9 @@ extern "C" {
     pub fn rt_frame_from_camera(position: *const f32, look_at: *const f32, up: *const f32, fov_degrees: f32, width: u32, height: u32,
                                 maxdepth: u32, ambient: *const f32, out: *mut rt_frame) -> c_int;
     pub fn rt_init(device: c_int) -> c_int;
+    pub fn rt_init_multi(ngpus: c_int) -> c_int;
+    pub fn rt_device_count() -> c_int;
+    pub fn rt_render_frame(frame: *const rt_frame, d_frame: *mut *const u32, stats: *mut rt_stats, count_work: c_int) -> c_int;
     pub fn rt_get_bvh_info(out: *mut rt_bvh_info) -> c_int;
     pub fn rt_upload_scene(scene: *const rt_scene) -> c_int;
     /// `flags`: `RT_BUILD_ON_GPU` builds the tree on the GPU (same split search, an order of magnitude faster for big scenes).

@@ -9,8 +9,8 @@ mkdir -p variants
 make -s -j8 >/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt \
     -Wno-unused-function -Wno-pass-failed "$@" -c csrc/render_kernels.hip -o variants/render_kernels_$name.o
-/opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "$@" -c csrc/rt_api.cpp -o variants/rt_api_$name.o
+/opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I/opt/rocm/include "$@" -c csrc/rt_api.cpp -o variants/rt_api_$name.o
 objs=$(ls csrc/*.o | grep -v -e render_kernels.o -e rt_api.o)
-/opt/rocm/bin/hipcc -shared -o variants/librt_amd_$name.so variants/render_kernels_$name.o variants/rt_api_$name.o $objs -fopenmp=libgomp -lz -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc -shared -o variants/librt_amd_$name.so variants/render_kernels_$name.o variants/rt_api_$name.o $objs -fopenmp=libgomp -lz -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 rm -f variants/render_kernels_$name.o variants/rt_api_$name.o
 echo variants/librt_amd_$name.so

@@ -113,3 +113,23 @@ def test_assemble_is_the_inverse_of_sharding():
         assert np.array_equal(shard.assemble_rows_host(parts, height, tile), frame)
         # tiles of consecutive rows stay together and rotate over the shards
         assert all(((shard.shard_row_indices(height, s, world, tile) // tile) % world == s).all() for s in range(world))
+
+
+def test_shard_rows_of_the_library_match_the_index_arithmetic():
+    import importlib
+    import __graft_entry__ as ge
+    rt = ge.load_package()
+    D = importlib.import_module("raytracer_rust_amd.distributed")
+    """rt_shard_rows (pure arithmetic, no GPU) is what the library's own multi-GPU frames and the per-process path size their
+    buffers with: every row belongs to exactly one shard, shard 0 never owns fewer rows than another (the stride of the gather
+    buffer), and the count agrees with the row lists the reassembly is tested with."""
+    L = rt.lib()
+    for height in (1, 7, 8, 9, 61, 480, 2160, 4320):
+        for n in (1, 2, 3, 4, 8):
+            for tile_rows in (1, 7, 8, 16):
+                rows = [int(L.rt_shard_rows(height, s, n, tile_rows)) for s in range(n)]
+                assert sum(rows) == height
+                assert rows[0] == max(rows)
+                for s in range(n):
+                    assert rows[s] == len(D.shard_row_indices(height, s, n, tile_rows))
+    assert L.rt_shard_rows(100, 3, 3, 8) == 0 and L.rt_shard_rows(100, 0, 0, 8) == 0 and L.rt_shard_rows(100, 0, 2, 0) == 0

@@ -438,6 +438,55 @@ def test_collective_path_on_a_single_rank_group():
 
 
 # ------------------------------------------------------------------ tree built on the GPU
+def test_frames_through_the_in_library_multi_gpu_path_on_one_gpu():
+    """rt_init_multi(1): one process, one RCCL communicator of size one.  Uploads go through the broadcast, frames through
+    tile rendering into the gather buffer and the reassembly kernel (the send/receive pairs need a second GPU), and must
+    come out as they do on the plain single-GPU path.  More than one GPU was never available to these tests."""
+    import torch
+    dragon = os.path.join(GOLDEN, "final_avec_bonus.scene")
+    tp64 = os.path.join(GOLDEN, "test_file", "jalon6", "tp64.test")
+    cfg = rt.ParsedConfigState().load_config_file(dragon)
+    single = rt.RayTracer.new(cfg)
+    single.render(count_work=True)
+    want_stats = single.last_stats
+    rt.shutdown()
+    try:
+        rt.init_multi(1)
+        assert rt.device_count() == 1
+        with pytest.raises(rt.RtError, match="already initialised"):
+            rt.init_multi(2)
+        tracer = rt.RayTracer.new(cfg)
+        img = tracer.render(count_work=True)
+        gold = rt.file_to_image(os.path.join(GOLDEN, "dragon3.png"))
+        assert np.array_equal(img.pixels() & 0xFFFFFF, gold.pixels())
+        got = tracer.last_stats
+        for k in ("primary", "shadow", "secondary", "nodes_visited", "prims_tested"):
+            assert got[k] == want_stats[k], k
+        # the frame left on the device, two lanes in flight, compared there
+        frame = cfg.frame()
+        tg = torch.from_numpy(gold.pixels().view(np.int32)).to("cuda:0")
+        ptrs = []
+        for lane in (0, 1, 0, 1):
+            rt.select_lane(lane)
+            ptr, _ = rt.render_frame(frame)
+            ptrs.append(ptr)
+        for lane in (0, 1):
+            rt.select_lane(lane)
+            rt.synchronize()
+            assert rt.compare_frames(ptrs[lane], (frame.width, frame.height), tg.data_ptr(), (gold.width, gold.height)) == 0
+        assert ptrs[0] == ptrs[2] and ptrs[0] != ptrs[1]
+        rt.select_lane(0)
+        # a small scene without a tree, at a height that is no multiple of the tile rows
+        cfg2 = rt.ParsedConfigState().load_config_file(tp64)
+        cfg2.set_size(97, 61)
+        img2 = rt.RayTracer.new(cfg2).render()
+        want2, _ = O.OracleScene.load(tp64).render(width=97, height=61)
+        assert np.array_equal(img2.pixels(), want2)
+    finally:
+        rt.shutdown()
+        rt.init(0)
+
+
 def _assert_gpu_built_scene_is_sound(info):
     blob = rt.download_scene_blob()
     rt.validate_blob(blob)                       # every reference in range, a proper tree, depth as declared
