@@ -95,7 +95,7 @@ typedef struct rt_stats {
 
 /* rt_build information about the tree the library built for the resident scene. */
 typedef struct rt_bvh_info {
-    uint32_t node_pairs;     /* 32-byte records: two 16-byte child boxes (15-bit grid) each */
+    uint32_t node_pairs;     /* 32-byte records: two 16-byte child boxes (16-bit grid coordinates) each */
     uint32_t leaves;
     uint32_t max_depth;      /* node pairs on the longest root-to-leaf path (at most 63)    */
     uint32_t max_leaf;       /* largest number of shapes in one leaf                        */

@@ -145,16 +145,16 @@ __device__ __forceinline__ float half_area3(const float* l, const float* h) {
 
 struct Grid { float origin[3], scale[3], inv_scale[3], pad_abs; };
 
-// Outward padding as the host builder applies it, then outward rounding onto the 15-bit grid with one
+// Outward padding as the host builder applies it, then outward rounding onto the scene grid (layout.h) with one
 // extra step of margin for the rounding of this very computation.
 __device__ __forceinline__ void quantise_box(const Grid& g, const float* l, const float* h, rtl::QuantChild* out) {
     for (int k = 0; k < 3; k++) {
         const float pad = fmaxf(fabsf(l[k]), fabsf(h[k])) * 4e-7f + g.pad_abs;
         // (times the rounded reciprocal: off by less than a hundredth of a step at the far end of the grid, the extra step covers it)
-        const float ql = floorf((l[k] - pad - g.origin[k]) * g.inv_scale[k]) - 1.0f;
-        const float qh = ceilf((h[k] + pad - g.origin[k]) * g.inv_scale[k]) + 1.0f;
-        out->q[k][0] = (uint16_t)fminf(fmaxf(ql, 0.0f), rtl::GRID_STEPS);
-        out->q[k][1] = (uint16_t)fminf(fmaxf(qh, 0.0f), rtl::GRID_STEPS);
+        const float ul = floorf((l[k] - pad - g.origin[k]) * g.inv_scale[k]) - 1.0f;
+        const float uh = ceilf((h[k] + pad - g.origin[k]) * g.inv_scale[k]) + 1.0f;
+        out->q[k][0] = (uint16_t)rtl::grid_code_below(fminf(fmaxf(ul, 0.0f), rtl::GRID_UNITS));
+        out->q[k][1] = (uint16_t)rtl::grid_code_above(fminf(fmaxf(uh, 0.0f), rtl::GRID_UNITS));
     }
 }
 
@@ -728,7 +728,7 @@ BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltSc
         ext[k] = hi - lo;
         const float pad = fmaxf(fabsf(lo), fabsf(hi)) * 4e-7f + in.pad_abs;
         g.origin[k] = nextafterf(lo - pad, -INFINITY);
-        float sc = (float)(((double)(hi + pad) - (double)g.origin[k]) / (double)rtl::GRID_STEPS);
+        float sc = (float)(((double)(hi + pad) - (double)g.origin[k]) / (double)rtl::GRID_UNITS);
         sc = nextafterf(nextafterf(sc, INFINITY), INFINITY);
         if (!(sc > 1e-30f)) sc = 1e-30f;
         g.scale[k] = sc; g.inv_scale[k] = 1.0f / sc; h.grid_origin[k] = g.origin[k]; h.grid_scale[k] = sc;

@@ -49,27 +49,39 @@ inline uint32_t region_log2_for(uint64_t tiles) {
     return l;
 }
 
-// LDS of one wavefront of the render kernel: a traversal stack of one entry per tree level plus a sentinel
-// (256 bytes per entry), and, when they fit beside it, the records of the reflection levels (maxdepth - 1 levels of
-// 1 KiB).  10 KiB per wavefront is what lets four wavefronts per SIMD share the 160 KiB of a compute unit; a frame
-// whose records do not fit keeps them in a global array instead (rtk_fold_in_lds says which).
-constexpr uint32_t RT_LDS_PER_WAVE = 10240;
+// Two builds of the render kernel, chosen per launch by the size of the resident scene:
+//   4 wavefronts per SIMD   128 vector registers (no spills), 10 KiB of LDS per wavefront.  For scenes that live in the
+//                           caches (the 7 MB dragon): the kernel is then bound by the chain of dependent traversal
+//                           steps and by vector ALU issue, and spill traffic costs more than a fifth wavefront gains.
+//   5 wavefronts per SIMD   96 vector registers (a few dozen bytes per lane spilled outside the inner loops), 8 KiB of
+//                           LDS.  For scenes beyond the caches (the 641 MB mesh): memory latency dominates and the
+//                           fifth wavefront hides more of it than the spills cost (42.4 against 46.8 ms on the 8K mesh).
+// LDS of one wavefront: a traversal stack of one entry per tree level plus a sentinel (256 bytes per entry), and, when
+// they fit beside it, the records of the reflection levels (maxdepth - 1 levels of 1 KiB); a frame whose records do not
+// fit keeps them in a global array instead.
+struct RenderPlan { int waves; bool fold_in_lds; };
+constexpr size_t RT_CACHE_RESIDENT_BYTES = 128u << 20;      // half the 256 MB memory-side cache
 inline uint32_t rtk_stack_entries(int stack_depth) { return (uint32_t)(stack_depth < 7 ? 8 : stack_depth + 1); }
-inline bool rtk_fold_in_lds(int stack_depth, uint32_t maxdepth) {
-#ifdef RT_FOLD_GLOBAL
-    return false;
+inline RenderPlan rtk_render_plan(size_t scene_bytes, int stack_depth, uint32_t maxdepth) {
+    RenderPlan p;
+#if defined(RT_FORCE_WAVES)
+    p.waves = RT_FORCE_WAVES;
 #else
-    if (maxdepth <= 1) return true;                    // no records at all
-    const uint64_t levels = (uint64_t)maxdepth - 1u;
-    return levels <= 8 && (uint64_t)rtk_stack_entries(stack_depth) * 256u + levels * 1024u <= RT_LDS_PER_WAVE;
+    p.waves = scene_bytes > RT_CACHE_RESIDENT_BYTES ? 5 : 4;
 #endif
+    const uint64_t budget = p.waves == 4 ? 10240 : 8192, levels = maxdepth > 1 ? (uint64_t)maxdepth - 1u : 0u;
+    p.fold_in_lds = levels == 0 || (levels <= 8 && (uint64_t)rtk_stack_entries(stack_depth) * 256u + levels * 1024u <= budget);
+#ifdef RT_FOLD_GLOBAL
+    p.fold_in_lds = levels == 0;
+#endif
+    return p;
 }
 
 // regions[order[i]] by decreasing cost into `order` (n <= MAX_SORTED_REGIONS), ties by index.
 extern "C" hipError_t rtk_launch_sort_regions(const uint32_t* d_cost, uint32_t n, uint32_t* d_order, hipStream_t stream);
 
 extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, uint32_t* d_out, float4* d_fold,
-                                        unsigned long long* d_counters, int stack_depth, int count, hipStream_t stream);
+                                        unsigned long long* d_counters, int stack_depth, RenderPlan plan, int count, hipStream_t stream);
 extern "C" hipError_t rtk_launch_assemble(const uint32_t* d_gathered, uint32_t stride_rows, uint32_t nshards, uint32_t tile_rows,
                                           uint32_t width, uint32_t height, uint32_t* d_frame, hipStream_t stream);
 // image_kernels.hip; pointers must be 16-byte aligned (d_rgb: 4-byte).

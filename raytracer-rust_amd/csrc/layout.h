@@ -8,15 +8,17 @@
 // every section 256-byte aligned.
 //
 //   node pair  32 B  two 16-byte child records side by side: {lo.x | hi.x << 16, lo.y | hi.y << 16,
-//                    lo.z | hi.z << 16, ref}, coordinates on a 15-bit grid.  The grid spans the box
-//                    of all tree shapes with 32767 steps per axis (header: grid_origin, grid_scale);
-//                    a coordinate q stands for the plane origin + q * scale.  Boxes are rounded
-//                    outwards onto the grid, so they only grow (by less than one step: 0.003 % of
-//                    the scene extent).  15 bits, so that one byte permute turns a coordinate into
-//                    the float 32768 + q (bytes {0, q.lo, q.hi, 0x47}) with no integer-to-float
-//                    conversion, and low and high plane of an axis share a word, so that the same
-//                    permute, with a per-ray selector, also sorts them into the plane the ray
-//                    enters through and the one it leaves through.  One 16-byte load per child.
+//                    lo.z | hi.z << 16, ref}, 16-bit coordinates on a grid that spans the box of all tree
+//                    shapes (header: grid_origin, grid_scale).  A coordinate q stands for the plane
+//                    origin + units(q) * scale with units(q) = q below 32768 and 2 q - 32768 from there
+//                    on: 98302 units per axis, planes one unit apart in the first third of the range and
+//                    two units apart beyond.  That is what the bit pattern gives for free: one byte permute
+//                    turns a coordinate into the float with the bytes {0, q.lo, q.hi, 0x47}, which is
+//                    32768 + units(q) (the top bit of q is the lowest exponent bit), with no integer-to-float
+//                    conversion; and because low and high plane of an axis share a word, the same permute,
+//                    with a per-ray selector, also sorts them into the plane the ray enters through and the
+//                    one it leaves through.  Boxes are rounded outwards onto the grid, so they only grow (by
+//                    less than two units: 0.002 % of the scene extent).  One 16-byte load per child.
 //   shape      48 B  three float4.  q0.w carries kind | material << 2, q1.w the shape's
 //                    position in the scene file (tie break), q2.w is spare.
 //                      triangle: q0.xyz = v0, q1.xyz = v1, q2.xyz = v2   (raw vertices: the
@@ -28,6 +30,7 @@
 #ifndef RT_LAYOUT_H
 #define RT_LAYOUT_H
 
+#include <math.h>
 #include <stdint.h>
 
 namespace rtl {
@@ -51,7 +54,16 @@ static_assert(sizeof(NodePair) == 64, "builder node pair is 64 bytes");
 struct QuantChild { uint16_t q[3][2]; uint32_t ref; };   // q[axis][0] = low plane, q[axis][1] = high plane
 struct QuantPair { QuantChild c[2]; };
 static_assert(sizeof(QuantChild) == 16 && sizeof(QuantPair) == 32, "device node pair must be 32 bytes");
-constexpr float GRID_STEPS = 32767.0f;
+constexpr float GRID_UNITS = 98302.0f;        // units(65535)
+#if defined(__HIPCC__)
+#define RT_LAYOUT_FN __host__ __device__ inline
+#else
+#define RT_LAYOUT_FN inline
+#endif
+RT_LAYOUT_FN float grid_units(uint32_t q) { return q < 32768u ? (float)q : (float)(2u * q - 32768u); }
+// Coordinate of the last plane at or below u units / the first plane at or above it (u already clamped to [0, GRID_UNITS]).
+RT_LAYOUT_FN uint32_t grid_code_below(float u) { return u < 32768.0f ? (uint32_t)floorf(u) : 32768u + (uint32_t)floorf((u - 32768.0f) * 0.5f); }
+RT_LAYOUT_FN uint32_t grid_code_above(float u) { return u <= 32768.0f ? (uint32_t)ceilf(u) : 32768u + (uint32_t)ceilf((u - 32768.0f) * 0.5f); }
 
 struct ShapeRec { float q0[3]; uint32_t kind_mat; float q1[3]; uint32_t order; float q2[3]; uint32_t spare; };
 static_assert(sizeof(ShapeRec) == 48, "shape record must be 48 bytes");
@@ -60,7 +72,7 @@ struct MaterialRec { float diffuse[3]; float shininess; float specular[3]; float
 struct LightRec { float v[3]; float kind; float color[3]; float pad; };
 
 constexpr uint32_t BLOB_MAGIC = 0x52544231u;   // "RTB1"
-constexpr uint32_t BLOB_VERSION = 3;
+constexpr uint32_t BLOB_VERSION = 4;
 
 struct BlobHeader {
     uint32_t magic, version;

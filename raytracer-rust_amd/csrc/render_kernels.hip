@@ -36,10 +36,6 @@
 
 #pragma clang fp contract(off)
 
-#ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 4
-#endif
-#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 
 namespace {
 
@@ -145,18 +141,17 @@ __device__ __forceinline__ bool shape_back_face(const float4 q0, const float4 q1
 }
 
 // ------------------------------------------------------------------ box culling (conservative)
-// Node boxes are 15-bit coordinates on the scene grid: plane q on an axis is origin + q * scale.
-// Along a ray o + t d its parameter is (origin + q*scale - o) / d = q * A + B with, per ray and
-// axis, A = scale / d and B = (origin - o) / d.  A child record keeps the low and the high plane
-// of an axis in one word; one byte permute per plane builds the float x = 32768 + q from it
-// (bytes {0, q.lo, q.hi, 0x47}: no integer-to-float conversion), and the ray's selector for that
-// permute already picks the plane the ray enters through (the low one when d >= 0) or the one it
-// leaves through, so no minimum / maximum per axis is needed afterwards.  The parameter is then
-// x * A + (B - 32768 A): one packed multiply-add gives entry and exit of an axis together.
-// The rounding of A, B, B - 32768 A, the shifted constant and the multiply-add is bounded by
-// delta = 2^-21 * (65535 |A| + |B|); the entry constant is lowered and the exit constant raised by
-// delta, so the computed interval always contains the exact one.  Nothing here decides a pixel: it
-// only has to keep every shape reachable that the exact tests would accept.
+// Node boxes are 16-bit coordinates on the scene grid: plane q on an axis is origin + units(q) * scale (layout.h).
+// Along a ray o + t d its parameter is (origin + units*scale - o) / d = units * A + B with, per ray and axis,
+// A = scale / d and B = (origin - o) / d.  A child record keeps the low and the high plane of an axis in one word;
+// one byte permute per plane builds the float x = 32768 + units(q) from it (bytes {0, q.lo, q.hi, 0x47}: no
+// integer-to-float conversion), and the ray's selector for that permute already picks the plane the ray enters
+// through (the low one when d >= 0) or the one it leaves through, so no minimum / maximum per axis is needed
+// afterwards.  The parameter is then x * A + (B - 32768 A): one packed multiply-add gives entry and exit of an
+// axis together.  The rounding of A, B, B - 32768 A, the shifted constant and the multiply-add is bounded by
+// delta = 2^-21 * (131072 |A| + |B|) (units go up to 98302); the entry constant is lowered and the exit constant
+// raised by delta, so the computed interval always contains the exact one.  Nothing here decides a pixel: it only
+// has to keep every shape reachable that the exact tests would accept.
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct RayBox {
     f2 Ax, Ay, Az;            // {A, A} per axis
@@ -175,7 +170,7 @@ __device__ __forceinline__ void make_axis(float scale, float origin, float limit
     const float inv = safe_inverse(d, limit);
     const float a = scale * inv;
     const float b = fminf(fmaxf((origin - o) * inv, -1e37f), 1e37f);
-    const float delta = 4.76837158203125e-07f * (65535.0f * fabsf(a) + fabsf(b));      // 2^-21 (...)
+    const float delta = 4.76837158203125e-07f * (131072.0f * fabsf(a) + fabsf(b));      // 2^-21 (...)
     const float shifted = b - 32768.0f * a;
     *A = f2{a, a};
     *B = f2{shifted - delta, shifted + delta};
@@ -194,7 +189,7 @@ __device__ __forceinline__ RayBox make_raybox(const DevScene& sc, V3 o, V3 d) {
 }
 
 __device__ __forceinline__ f2 planes_of(uint32_t axis_word, uint32_t sel_in, uint32_t sel_out) {
-    const uint32_t K = 0x47000000u;       // exponent byte of 32768 + q
+    const uint32_t K = 0x47000000u;       // exponent byte of 32768 + units(q)
     return f2{__uint_as_float(__builtin_amdgcn_perm(K, axis_word, sel_in)), __uint_as_float(__builtin_amdgcn_perm(K, axis_word, sel_out))};
 }
 
@@ -362,8 +357,8 @@ extern __shared__ uint32_t s_stack[];
 // FOLD_LDS: the {local colour, material} records of the reflection levels live in LDS behind the stacks
 // ([level][lane], 16 bytes each) instead of in the global `fold` array ([level][pixel]).
 template <bool COUNT, bool FOLD_LDS>
-__global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, DevFrame f, uint32_t* __restrict__ out, float4* __restrict__ fold,
-                                                    unsigned long long* __restrict__ counters, uint32_t stack_entries) {
+__device__ __forceinline__ void render_pixel_tile(const DevScene& sc, const DevFrame& f, uint32_t* __restrict__ out, float4* __restrict__ fold,
+                                                   unsigned long long* __restrict__ counters, uint32_t stack_entries) {
     const uint32_t lane = threadIdx.x;
     float4* const fold_lds = (float4*)(s_stack + stack_entries * 64u) + lane;
     // Which 8x8 pixel tile this wavefront renders.  Workgroups are dealt round-robin over the 8
@@ -490,6 +485,20 @@ __global__ __launch_bounds__(64) RT_WAVES_ATTR void render_kernel(DevScene sc, D
     }
 }
 
+// The two builds (device_types.h: RenderPlan): the same code under a register budget of 128 and of 96.
+template <bool COUNT, bool FOLD_LDS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_kernel(DevScene sc, DevFrame f, uint32_t* __restrict__ out,
+                                                                                              float4* __restrict__ fold, unsigned long long* __restrict__ counters,
+                                                                                              uint32_t stack_entries) {
+    render_pixel_tile<COUNT, FOLD_LDS>(sc, f, out, fold, counters, stack_entries);
+}
+template <bool COUNT, bool FOLD_LDS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_kernel_5(DevScene sc, DevFrame f, uint32_t* __restrict__ out,
+                                                                                                float4* __restrict__ fold, unsigned long long* __restrict__ counters,
+                                                                                                uint32_t stack_entries) {
+    render_pixel_tile<COUNT, FOLD_LDS>(sc, f, out, fold, counters, stack_entries);
+}
+
 // Regions by decreasing measured cost (bitonic sort of one workgroup in LDS; keys cost << 32 | ~index so that
 // equal costs keep index order).
 // `padded`: the power of two the n keys are padded to (with keys that sort last).
@@ -526,7 +535,7 @@ __global__ void assemble_kernel(const uint32_t* __restrict__ gathered, uint32_t 
 
 // ------------------------------------------------------------------ launchers (called from rt_api.cpp)
 extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, uint32_t* d_out, float4* d_fold,
-                                        unsigned long long* d_counters, int stack_depth, int count, hipStream_t stream) {
+                                        unsigned long long* d_counters, int stack_depth, RenderPlan plan, int count, hipStream_t stream) {
     uint32_t tiles_x = (f->width + 7u) >> 3, tiles_y = (f->local_rows + 7u) >> 3;
     uint64_t blocks = (uint64_t)tiles_x * tiles_y;
     if (blocks == 0) return hipSuccess;
@@ -540,19 +549,21 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     const uint32_t entries = rtk_stack_entries(stack_depth);
     if (entries > 64) return hipErrorInvalidValue;
     size_t lds_bytes = (size_t)entries * 64 * sizeof(uint32_t);
-    const bool fold_lds = rtk_fold_in_lds(stack_depth, f->maxdepth);
-    if (fold_lds) lds_bytes += (size_t)(f->maxdepth - 1u) * 64 * sizeof(float4);
+    const bool fold_lds = plan.fold_in_lds;
+    if (fold_lds && f->maxdepth > 1) lds_bytes += (size_t)(f->maxdepth - 1u) * 64 * sizeof(float4);
     else if (f->maxdepth > 1 && !d_fold) return hipErrorInvalidValue;
 #ifdef RT_DIAG_LDS_PAD
     { static const char* pad = getenv("RT_DIAG_LDS_PAD"); if (pad) lds_bytes = std::max(lds_bytes, (size_t)atoi(pad)); }   // occupancy experiments (scripts/ab_occ.sh)
 #endif
-    if (count) {
-        if (fold_lds) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries);
-        else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries);
+#define RT_LAUNCH(KERNEL, C, F) hipLaunchKernelGGL((KERNEL<C, F>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries)
+    if (plan.waves == 5) {
+        if (count) { if (fold_lds) RT_LAUNCH(render_kernel_5, true, true); else RT_LAUNCH(render_kernel_5, true, false); }
+        else { if (fold_lds) RT_LAUNCH(render_kernel_5, false, true); else RT_LAUNCH(render_kernel_5, false, false); }
     } else {
-        if (fold_lds) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries);
-        else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries);
+        if (count) { if (fold_lds) RT_LAUNCH(render_kernel, true, true); else RT_LAUNCH(render_kernel, true, false); }
+        else { if (fold_lds) RT_LAUNCH(render_kernel, false, true); else RT_LAUNCH(render_kernel, false, false); }
     }
+#undef RT_LAUNCH
     return hipGetLastError();
 }
 

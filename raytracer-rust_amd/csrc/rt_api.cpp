@@ -134,7 +134,7 @@ void point_at_blob(Device& dev, const rtl::BlobHeader& h) {
     dev.dsc.n_list = h.n_list_shapes; dev.dsc.n_lights = h.n_lights; dev.dsc.root_ref = h.root_ref; dev.dsc.finite_shading = h.finite_shading;
     for (int k = 0; k < 3; k++) {
         dev.dsc.grid_origin[k] = h.grid_origin[k]; dev.dsc.grid_scale[k] = h.grid_scale[k];
-        dev.dsc.inv_limit[k] = std::fmin(1e30f, 1e33f / std::fmax(h.grid_scale[k], 1e-30f));
+        dev.dsc.inv_limit[k] = std::fmin(1e30f, 1e32f / std::fmax(h.grid_scale[k], 1e-30f));     // 131072 * scale / d stays finite
     }
 }
 
@@ -151,7 +151,7 @@ int scene_is_resident(const rtl::BlobHeader& h) {
         }
         NCCL_TRY(ncclGroupStart());
         for (int d = 0; d < g.ndev; d++)
-            NCCL_TRY(ncclBroadcast(first().d_blob, g.devs[d].d_blob, bytes, ncclUint8, 0, g.comms[d], cur(d).stream));
+            NCCL_TRY(ncclBroadcast(g.devs[d].d_blob, g.devs[d].d_blob, bytes, ncclUint8, 0, g.comms[d], cur(d).stream));     // in place on every GPU
         NCCL_TRY(ncclGroupEnd());
         for (int d = g.ndev - 1; d >= 0; d--) {
             if (use(d)) return 1;
@@ -248,11 +248,12 @@ int enqueue_shard(int d, const rt_frame* frame, uint32_t shard, uint32_t nshards
     if (!d_out) return fail("output buffer is NULL");
     size_t npix = (size_t)local_rows * frame->width;
     uint32_t levels = frame->maxdepth > 1 ? frame->maxdepth - 1 : 0;
-    if (!rtk_fold_in_lds((int)g.hdr.max_depth, frame->maxdepth) && ensure_fold(lane, npix, levels)) return 1;
+    const RenderPlan plan = rtk_render_plan(g.devs[d].blob_bytes, (int)g.hdr.max_depth, frame->maxdepth);
+    if (!plan.fold_in_lds && ensure_fold(lane, npix, levels)) return 1;
     if (count_work) HIP_TRY(hipMemsetAsync(lane.d_counters, 0, 8 * sizeof(unsigned long long), lane.stream));
     if (plan_regions(lane, *frame, &f)) return 1;
     if (timed) HIP_TRY(hipEventRecord(lane.ev0, lane.stream));
-    HIP_TRY(rtk_launch_render(&g.devs[d].dsc, &f, d_out, lane.d_fold, lane.d_counters, (int)g.hdr.max_depth, count_work, lane.stream));
+    HIP_TRY(rtk_launch_render(&g.devs[d].dsc, &f, d_out, lane.d_fold, lane.d_counters, (int)g.hdr.max_depth, plan, count_work, lane.stream));
     if (f.region_cost) HIP_TRY(rtk_launch_sort_regions(f.region_cost, f.n_regions, lane.d_region_order, lane.stream));
     if (timed) HIP_TRY(hipEventRecord(lane.ev1, lane.stream));
     return 0;

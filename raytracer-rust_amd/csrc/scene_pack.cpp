@@ -111,8 +111,6 @@ bool validate_blob(const uint8_t* blob, size_t bytes, std::string* err) {
         seen[idx] = 1; reached++;
         if (depth > h.max_depth || depth > TREE_DEPTH_LIMIT) { *err = "scene blob: tree deeper than its header says"; return false; }
         for (int c = 0; c < 2; c++) {
-            for (int k = 0; k < 3; k++)
-                if (pairs[idx].c[c].q[k][0] > 32767u || pairs[idx].c[c].q[k][1] > 32767u) { *err = "scene blob: node box off the 15-bit grid"; return false; }
             uint32_t ref = pairs[idx].c[c].ref;
             if (ref == rtl::REF_EMPTY) continue;
             if (ref & rtl::REF_LEAF) {
@@ -313,7 +311,7 @@ bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info
                                 h.off_lights + (size_t)s.nlights * sizeof(rtl::LightRec)};
         for (size_t e : ends) std::memset(blob->data() + e, 0, align256(e) - e);
     }
-    // Quantise the (already padded) builder boxes outwards onto the 15-bit scene grid.
+    // Quantise the (already padded) builder boxes outwards onto the scene grid (layout.h).
     {
         // The two children of the root bound everything below them.
         double glo[3] = {0, 0, 0}, ghi[3] = {0, 0, 0};
@@ -323,7 +321,7 @@ bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info
         }
         for (int k = 0; k < 3; k++) {
             h.grid_origin[k] = std::nextafter((float)glo[k], -INFINITY);
-            float sc = (float)((ghi[k] - (double)h.grid_origin[k]) / (double)rtl::GRID_STEPS);
+            float sc = (float)((ghi[k] - (double)h.grid_origin[k]) / (double)rtl::GRID_UNITS);
             sc = std::nextafter(std::nextafter(sc, INFINITY), INFINITY);
             if (!(sc > 1e-30f)) sc = 1e-30f;
             h.grid_scale[k] = sc;
@@ -336,12 +334,12 @@ bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info
                 const rtl::ChildBox& b = bvh.pairs[(size_t)i].c[c];
                 for (int k = 0; k < 3; k++) {
                     const double o = h.grid_origin[k], sc = h.grid_scale[k];
-                    double ql = std::floor(((double)b.lo[k] - o) / sc), qh = std::ceil(((double)b.hi[k] - o) / sc);
-                    while (ql > 0 && o + ql * sc > (double)b.lo[k]) ql -= 1;         // the grid plane must not lie inside the box
-                    while (qh < rtl::GRID_STEPS && o + qh * sc < (double)b.hi[k]) qh += 1;
-                    if (ql < 0) ql = 0;
-                    if (qh > rtl::GRID_STEPS) qh = rtl::GRID_STEPS;
-                    if (o + ql * sc > (double)b.lo[k] || o + qh * sc < (double)b.hi[k]) ok = false;
+                    const double ul = std::min(std::max(((double)b.lo[k] - o) / sc, 0.0), (double)rtl::GRID_UNITS);
+                    const double uh = std::min(std::max(((double)b.hi[k] - o) / sc, 0.0), (double)rtl::GRID_UNITS);
+                    uint32_t ql = rtl::grid_code_below((float)std::floor(ul)), qh = rtl::grid_code_above((float)std::ceil(uh));
+                    while (ql > 0 && o + (double)rtl::grid_units(ql) * sc > (double)b.lo[k]) ql -= 1;         // the grid plane must not lie inside the box
+                    while (qh < 65535u && o + (double)rtl::grid_units(qh) * sc < (double)b.hi[k]) qh += 1;
+                    if (o + (double)rtl::grid_units(ql) * sc > (double)b.lo[k] || o + (double)rtl::grid_units(qh) * sc < (double)b.hi[k]) ok = false;
                     qp[i].c[c].q[k][0] = (uint16_t)ql; qp[i].c[c].q[k][1] = (uint16_t)qh;
                 }
                 qp[i].c[c].ref = b.ref;

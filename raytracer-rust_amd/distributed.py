@@ -79,11 +79,13 @@ class ShardedRenderer:
     (or `lanes` more frames have been enqueued) and the device has been synchronised.
     """
 
-    def __init__(self, device, render_rows, assemble, stream_ctx=None, tile_rows=TILE_ROWS, always_gather=False, select_lane=None, lanes=None):
+    def __init__(self, device, render_rows, assemble, stream_ctx=None, tile_rows=TILE_ROWS, always_gather=False, select_lane=None, lanes=None,
+                 group=None):
         import contextlib
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        self.group = group              # process group of the collectives (None: the default group)
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.device = device
@@ -153,7 +155,7 @@ class ShardedRenderer:
                 views = self._gather_lists.get((W, H, lane))
                 if views is None:
                     views = self._gather_lists[(W, H, lane)] = list(gathered[lane].unbind(0))
-            work = self.dist.gather(local[lane], views, dst=0, async_op=True)
+            work = self.dist.gather(local[lane], views, dst=0, group=self.group, async_op=True)
             self._pending[lane] = (work, W, H)
         return frame[lane]
 
@@ -165,7 +167,7 @@ class ShardedRenderer:
         self._select_lane(self._slot)
 
 
-def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gather=False, gpu_build=False, lanes=None):
+def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gather=False, gpu_build=False, lanes=None, group=None):
     """ShardedRenderer on one MI355X: uploads (rank 0) or receives (other ranks) the scene and wires the
     library's tile rendering and frame assembly in.  Returns (renderer, bvh_info or None)."""
     import torch
@@ -190,7 +192,7 @@ def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gathe
             _, nbytes = rt.scene_blob()
             buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             rt.copy_scene_blob(buf.data_ptr(), nbytes)
-        buf = broadcast_bytes(buf, device, src=0)
+        buf = broadcast_bytes(buf, device, src=0, group=group)
         if rank != 0:
             torch.cuda.synchronize(device)
             rt.adopt_scene_blob(buf.data_ptr(), buf.numel())
@@ -203,6 +205,6 @@ def gpu_renderer(rt, device_index, scene=None, tile_rows=TILE_ROWS, always_gathe
         rt.assemble_tiles(gathered.data_ptr(), gathered.shape[1], gathered.shape[0], frame.shape[1], frame.shape[0], frame.data_ptr(), tile_rows=rows)
 
     r = ShardedRenderer(device, render_rows, assemble, stream_ctx=lambda lane: torch.cuda.stream(ext[lane]), tile_rows=tile_rows,
-                        always_gather=always_gather, select_lane=rt.select_lane, lanes=lanes)
+                        always_gather=always_gather, select_lane=rt.select_lane, lanes=lanes, group=group)
     r.ext_streams, r._keep_blob = ext, keep
     return r, info

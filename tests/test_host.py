@@ -336,7 +336,7 @@ HDR = struct.Struct("<IIQ5Q5II3IfI3f3f")
 def _read_blob(blob):
     (magic, ver, total, o_nodes, o_tree, o_list, o_mat, o_light, n_pairs, n_tree, n_list, n_mat, n_light, root,
      max_depth, max_leaf, n_leaves, sah, finite, gx, gy, gz, sx, sy, sz) = HDR.unpack_from(blob.tobytes()[:HDR.size])
-    assert magic == 0x52544231 and ver == 3 and total == len(blob)
+    assert magic == 0x52544231 and ver == 4 and total == len(blob)
     nodes = blob[o_nodes:o_nodes + 32 * n_pairs].view(np.uint32).reshape(n_pairs, 8)
     tree = blob[o_tree:o_tree + 48 * n_tree].view(np.uint32).reshape(n_tree, 12)
     lst = blob[o_list:o_list + 48 * n_list].view(np.uint32).reshape(n_list, 12)
@@ -349,10 +349,12 @@ def _check_tree(b):
     tf = tree.view(np.float32)
 
     def child_box(ref, c):
-        # 15-bit grid coordinates (low | high << 16 per axis) -> the exact planes they stand for (float64: exact for these products)
+        # 16-bit grid coordinates (low | high << 16 per axis) -> the exact planes they stand for: q units below 32768,
+        # 2 q - 32768 from there on (float64: exact for these products)
         w = nodes[ref, 4 * c:4 * c + 3]
-        lo, hi = np.float64(w & 0xFFFF), np.float64(w >> 16)
-        assert (hi < 32768).all() and (lo <= hi).all()
+        units = lambda q: np.where(q < 32768, q, 2.0 * q - 32768.0)
+        lo, hi = units(np.float64(w & 0xFFFF)), units(np.float64(w >> 16))
+        assert (lo <= hi).all()
         return b["origin"] + lo * b["scale"], b["origin"] + hi * b["scale"]
     seen = np.zeros(len(tree), dtype=np.int32)
     max_depth = 0
@@ -385,7 +387,7 @@ def _check_tree(b):
         for c in (0, 1):
             clo, chi = child_box(ref, c)
             if lo is not None:      # a child may stick out of its parent by the padding and one grid step, not more
-                slack = 2 * b["scale"] + 1e-5 * (np.abs(lo) + np.abs(hi)) + 1e-4 * (hi - lo).max()
+                slack = 4 * b["scale"] + 1e-5 * (np.abs(lo) + np.abs(hi)) + 1e-4 * (hi - lo).max()
                 assert (clo >= lo - slack).all() and (chi <= hi + slack).all()
             cref = int(nodes[ref, 4 * c + 3])
             stack.append((cref, depth + 1, clo, chi))
