@@ -13,7 +13,7 @@ PASSES=${PASSES:-"fetch write sq1 sq2 tcp"}
 run_pass() {
     name=$1; shift
     case " $PASSES " in *" $name "*) ;; *) return 0;; esac
-    timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- python3 "$ROOT/scripts/render_once.py" 3 $EXTRA > "$OUT/$name.log" 2>&1
+    timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- python3 "$ROOT/scripts/render_once.py" 3 $EXTRA > "$OUT/$name.log" 2>&1
     rc=$?
     echo "pass $name rc=$rc"
     return $rc

@@ -10,7 +10,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 KERNELS = ("render_kernel", "closest_kernel", "shade_kernel", "fold_kernel")
-acc = defaultdict(list)
+acc = defaultdict(list)          # counter -> one sum per pass file that collected it
 per_kernel = defaultdict(lambda: defaultdict(float))      # kernel -> counter -> sum over the dispatches of ONE frame (the last)
 for path in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
     per_dispatch = defaultdict(float)
@@ -24,11 +24,14 @@ for path in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))
     ids = sorted({d for d, _, _ in per_dispatch})
     folds = sorted({d for d, _, k in per_dispatch if k in ("fold_kernel", "render_kernel")})
     lo = folds[-2] if len(folds) >= 2 else -1
+    in_file = defaultdict(float)
     for (d, name, kn), v in per_dispatch.items():
         if d > lo:
-            acc[name].append(v)
-            per_kernel[kn][name] += v
-out = {k: sum(v) for k, v in acc.items()}
+            in_file[name] += v
+            per_kernel[kn][name] = v if name not in per_kernel[kn] else per_kernel[kn][name]      # (a counter collected in two passes is kept once)
+    for name, v in in_file.items():
+        acc[name].append(v)
+out = {k: sum(v) / len(v) for k, v in acc.items()}
 d = dict(out)
 if "FETCH_SIZE" in d:
     # FETCH_SIZE/WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte requests of wide
