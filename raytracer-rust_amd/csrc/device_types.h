@@ -56,12 +56,12 @@ inline uint32_t region_log2_for(uint64_t tiles) {
 //   5 wavefronts per SIMD   96 vector registers (a few dozen bytes per lane spilled outside the inner loops), 8 KiB of
 //                           LDS.  For scenes beyond the caches (the 641 MB mesh): memory latency dominates and the
 //                           fifth wavefront hides more of it than the spills cost (42.4 against 46.8 ms on the 8K mesh).
-// LDS of one wavefront: a traversal stack of one entry per tree level plus a sentinel (256 bytes per entry), and, when
+// LDS of one wavefront: a traversal stack of one entry per tree level plus two sentinels (256 bytes per entry), and, when
 // they fit beside it, the records of the reflection levels (maxdepth - 1 levels of 1 KiB); a frame whose records do not
 // fit keeps them in a global array instead.
 struct RenderPlan { int waves; bool fold_in_lds; };
 constexpr size_t RT_CACHE_RESIDENT_BYTES = 128u << 20;      // half the 256 MB memory-side cache
-inline uint32_t rtk_stack_entries(int stack_depth) { return (uint32_t)(stack_depth < 7 ? 8 : stack_depth + 1); }
+inline uint32_t rtk_stack_entries(int stack_depth) { return (uint32_t)(stack_depth < 6 ? 8 : stack_depth + 2); }     // two sentinels
 inline RenderPlan rtk_render_plan(size_t scene_bytes, int stack_depth, uint32_t maxdepth) {
     RenderPlan p;
 #if defined(RT_FORCE_WAVES)

@@ -233,31 +233,38 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
     if (cur == REF_EMPTY) return;
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = best->prim == NO_PRIM ? INF : prune_limit(best->t);
-    uint32_t* top = stack + 64;                         // next free entry; entry 0 of every lane's stack holds REF_EMPTY: popping needs no emptiness test
+    // Entries 0 and 1 of every lane's stack hold REF_EMPTY: popping needs no emptiness test, and the two entries below
+    // the top can always be read.  `top` is the next free entry.
+    uint32_t* top = stack + 128;
     // All lanes descend through inner nodes until each has reached a leaf (or run out of nodes),
     // then all test their leaves together.  A lane that reaches its leaf early sets it aside and
     // keeps descending towards its next one instead of idling (it then tests both).
+    // A step is straight-line code: the two entries below the top are read while the node is on its way (a pop, and a
+    // pop right after a pop, then cost no LDS round trip of their own), the rest are selects.
     uint32_t held = 0;                                  // leaf set aside (leaf references are never 0)
     for (;;) {
         while (!(cur & REF_LEAF)) {
             const uint4* n = (const uint4*)((const char*)sc.nodes + (cur << 5));   // 32-byte pairs; a 32-bit offset keeps the address in one register
             const uint4 c0 = n[0], c1 = n[1];
+            uint32_t below = top[-64], below2 = top[-128];
+            asm volatile("" : "+v"(below), "+v"(below2));       // keeps the reads here, under the node loads, instead of behind the box tests
             float t0, t1;
             bool h0 = slab(c0, rb, tlim, &t0);
             bool h1 = slab(c1, rb, tlim, &t1);
             if (COUNT) { cnt->nodes += 2; if (first_active_lane()) cnt->wave_node_iters++; }
-            uint32_t r0 = c0.w, r1 = c1.w;
-            if (h0 && h1) {
-                bool swap = t1 < t0;
-                *top = swap ? r0 : r1; top += 64;
-                cur = swap ? r1 : r0;
-            } else if (h0) cur = r0;
-            else if (h1) cur = r1;
-            else { top -= 64; cur = *top; }
-            if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {
-                held = cur;
-                top -= 64; cur = *top;
-            }
+            const uint32_t r0 = c0.w, r1 = c1.w;
+            const bool both = h0 && h1, any = h0 || h1, swap = t1 < t0;
+            const uint32_t far_child = swap ? r0 : r1;
+            if (both) *top = far_child;
+            // where the step leads, and what a pop would return from there
+            const uint32_t next = both ? (swap ? r1 : r0) : (any ? (h0 ? r0 : r1) : below);
+            const uint32_t under = both ? far_child : (any ? below : below2);
+            top += both ? 64 : (any ? 0 : -64);
+            // a lane without a leaf in hand sets the one it has reached aside and goes on with what lies under it
+            const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
+            held = take ? next : held;
+            cur = take ? under : next;
+            top -= take ? 64 : 0;
             if (__builtin_amdgcn_ballot_w64(held == 0 && !(cur & REF_LEAF)) == 0) break;    // nobody is still looking for a first leaf
         }
         if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf
@@ -266,6 +273,8 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
         }
         while (held != 0) {
             uint32_t first = (held & ~REF_LEAF) >> 3, count = (held & 7u) + 1u;
+            uint32_t below = top[-64];
+            asm volatile("" : "+v"(below));                     // read under the shape loads
             for (uint32_t k = 0; k < count; k++) {
                 const float4* p = sc.tree + 3 * (size_t)(first + k);
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2];
@@ -279,7 +288,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             held = 0;
             if ((cur & REF_LEAF) && cur != REF_EMPTY) {
                 held = cur;
-                top -= 64; cur = *top;
+                top -= 64; cur = below;
             }
         }
         if (cur == REF_EMPTY) break;
@@ -308,29 +317,33 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
     if (cur == REF_EMPTY) return false;
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = point_light ? prune_limit(light_dist) : INF;
-    uint32_t* top = stack + 64;
+    uint32_t* top = stack + 128;                        // as in closest_hit
     while (cur != REF_EMPTY) {
         while (!(cur & REF_LEAF)) {
             const uint4* n = (const uint4*)((const char*)sc.nodes + (cur << 5));   // 32-byte pairs; a 32-bit offset keeps the address in one register
             const uint4 c0 = n[0], c1 = n[1];
+            uint32_t below = top[-64];
+            asm volatile("" : "+v"(below));       // keeps the read here, under the node loads, instead of behind the box tests
             float t0, t1;
             bool h0 = slab(c0, rb, tlim, &t0);
             bool h1 = slab(c1, rb, tlim, &t1);
             if (COUNT) { cnt->nodes += 2; if (first_active_lane()) cnt->wave_node_iters++; }
-            uint32_t r0 = c0.w, r1 = c1.w;
-            if (h0 && h1) { *top = r1; top += 64; cur = r0; }
-            else if (h0) cur = r0;
-            else if (h1) cur = r1;
-            else { top -= 64; cur = *top; }
+            const uint32_t r0 = c0.w, r1 = c1.w;
+            const bool both = h0 && h1;
+            if (both) *top = r1;
+            cur = h0 ? r0 : (h1 ? r1 : below);
+            top += both ? 64 : ((h0 || h1) ? 0 : -64);
         }
         if (cur != REF_EMPTY) {
             uint32_t first = (cur & ~REF_LEAF) >> 3, count = (cur & 7u) + 1u;
+            uint32_t below = top[-64];
+            asm volatile("" : "+v"(below));       // read under the shape loads
             for (uint32_t k = 0; k < count; k++) {
                 const float4* p = sc.tree + 3 * (size_t)(first + k);
                 if (COUNT) { cnt->prims++; if (first_active_lane()) cnt->wave_prim_iters++; }
                 if (occludes(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
             }
-            top -= 64; cur = *top;
+            top -= 64; cur = below;
         }
     }
     return false;
@@ -381,7 +394,7 @@ __device__ __forceinline__ void render_pixel_tile(const DevScene& sc, const DevF
     }
     const uint32_t x = tile_x * 8u + (lane & 7u), r = tile_y * 8u + (lane >> 3);
     uint32_t* stack = s_stack + lane;
-    stack[0] = REF_EMPTY;
+    stack[0] = REF_EMPTY; stack[64] = REF_EMPTY;
     Counters cnt = {0u, 0u, 0u, 0u, 0u, 0u};
     const bool live = x < f.width && r < f.local_rows;
     if (live) {
@@ -547,7 +560,7 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     dim3 grid((uint32_t)blocks), block(64);
     // One stack entry per tree level plus the sentinel.
     const uint32_t entries = rtk_stack_entries(stack_depth);
-    if (entries > 64) return hipErrorInvalidValue;
+    if (entries > 65) return hipErrorInvalidValue;
     size_t lds_bytes = (size_t)entries * 64 * sizeof(uint32_t);
     const bool fold_lds = plan.fold_in_lds;
     if (fold_lds && f->maxdepth > 1) lds_bytes += (size_t)(f->maxdepth - 1u) * 64 * sizeof(float4);
