@@ -215,7 +215,7 @@ def main():
                     rt.select_lane(lane)
                     rt.synchronize()
                 rt.select_lane(0)
-            for d in range(torch.cuda.device_count() if mode == "library" else 1):
+            for d in range(world if mode == "library" else 1):
                 torch.cuda.synchronize(torch.device("cuda", d) if mode == "library" else device)
         if dist.is_initialized():
             dist.barrier()
