@@ -59,6 +59,9 @@ inline uint32_t region_log2_for(uint64_t tiles) {
 // LDS of one wavefront: a traversal stack of one entry per tree level plus two sentinels (256 bytes per entry), and, when
 // they fit beside it, the records of the reflection levels (maxdepth - 1 levels of 1 KiB); a frame whose records do not
 // fit keeps them in a global array instead.
+#ifndef RT_HIGH_WAVES
+#define RT_HIGH_WAVES 5          // wavefronts per SIMD of the second build
+#endif
 struct RenderPlan { int waves; bool fold_in_lds; };
 constexpr size_t RT_CACHE_RESIDENT_BYTES = 128u << 20;      // half the 256 MB memory-side cache
 inline uint32_t rtk_stack_entries(int stack_depth) { return (uint32_t)(stack_depth < 6 ? 8 : stack_depth + 2); }     // two sentinels
@@ -69,7 +72,7 @@ inline RenderPlan rtk_render_plan(size_t scene_bytes, int stack_depth, uint32_t 
 #else
     p.waves = scene_bytes > RT_CACHE_RESIDENT_BYTES ? 5 : 4;
 #endif
-    const uint64_t budget = p.waves == 4 ? 10240 : 8192, levels = maxdepth > 1 ? (uint64_t)maxdepth - 1u : 0u;
+    const uint64_t budget = p.waves == 4 ? 10240 : (RT_HIGH_WAVES == 5 ? 8192 : 6656), levels = maxdepth > 1 ? (uint64_t)maxdepth - 1u : 0u;
     p.fold_in_lds = levels == 0 || (levels <= 8 && (uint64_t)rtk_stack_entries(stack_depth) * 256u + levels * 1024u <= budget);
 #ifdef RT_FOLD_GLOBAL
     p.fold_in_lds = levels == 0;

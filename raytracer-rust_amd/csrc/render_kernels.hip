@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     render_pixel_tile<COUNT, FOLD_LDS>(sc, f, out, fold, counters, stack_entries);
 }
 template <bool COUNT, bool FOLD_LDS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_kernel_5(DevScene sc, DevFrame f, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_HIGH_WAVES, RT_HIGH_WAVES))) void render_kernel_5(DevScene sc, DevFrame f, uint32_t* __restrict__ out,
                                                                                                 float4* __restrict__ fold, unsigned long long* __restrict__ counters,
                                                                                                 uint32_t stack_entries) {
     render_pixel_tile<COUNT, FOLD_LDS>(sc, f, out, fold, counters, stack_entries);

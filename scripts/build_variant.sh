@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../raytracer-rust_amd"
 name=$1; shift
 mkdir -p variants
 make -s -j8 >/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize \
     -Wno-unused-function -Wno-pass-failed "$@" -c csrc/render_kernels.hip -o variants/render_kernels_$name.o
 /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I/opt/rocm/include "$@" -c csrc/rt_api.cpp -o variants/rt_api_$name.o
 objs=$(ls csrc/*.o | grep -v -e render_kernels.o -e rt_api.o)
