@@ -311,12 +311,13 @@ def main():
         achieved = alg_bytes / launches / (k_ms * 1e-3) / 1e9
         pmc = load_counters(args.config)
         # Neither workload is carried by HBM: measured HBM traffic per launch (traffic) is 0.3 % of the algorithmic bytes on the
-        # dragon (7 MB scene, L2 hit rate 98 %) and 9 % on the mesh (641 MB scene, L2 hit rate 79 %, the rest mostly from the
+        # dragon (7 MB scene, L2 hit rate 98 %) and 5 % on the mesh (641 MB scene, L2 hit rate 85 %, the rest mostly from the
         # 256 MB memory-side cache), so the memory-side bound of the traversal is the aggregate L2 bandwidth for both.
         bound, peak = "l2", L2_PEAK_GBS
         note = ("algorithmic bytes = 32 B x boxes tested + 48 B x shapes tested + 4 B x pixels, served by the caches (see traffic for what "
-                "reaches HBM), hence compared with the aggregate L2 bandwidth; what limits the kernel is the chain of dependent traversal "
-                "steps per wavefront at 4 (mesh: 5) wavefronts per SIMD, with vector ALU issue at valu_issue_frac")
+                "reaches HBM), hence compared with the aggregate L2 bandwidth; what limits the kernel is vector ALU issue (valu_issue_frac of "
+                "the SIMDs' issue slots, at 4 wavefronts per SIMD, mesh: 5) spent at valu_lane_use of the lanes: a wavefront runs as long "
+                "as its slowest ray")
         roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                     "traffic": pmc.get("hbm_bytes_per_launch"),
                     "kernel": "render_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes / launches,
