@@ -148,9 +148,12 @@ __device__ __forceinline__ bool shape_back_face(const float4 q0, const float4 q1
 // integer-to-float conversion), and the ray's selector for that permute already picks the plane the ray enters
 // through (the low one when d >= 0) or the one it leaves through, so no minimum / maximum per axis is needed
 // afterwards.  The parameter is then x * A + (B - 32768 A): one packed multiply-add gives entry and exit of an
-// axis together.  The rounding of A, B, B - 32768 A, the shifted constant and the multiply-add is bounded by
-// delta = 2^-21 * (131072 |A| + |B|) (units go up to 98302); the entry constant is lowered and the exit constant
-// raised by delta, so the computed interval always contains the exact one.  Nothing here decides a pixel: it only
+// axis together.  With e = 2^-24: 1/d comes from the hardware reciprocal (off by at most 2e), so A is within 3e and
+// B within 4e of their exact values, and B - 32768 A, the shifted constant and the multiply-add round once each,
+// every time to a value below 131072 |A| + |B|; with units up to 98302 that is an error below
+// e (688122 |A| + 7 |B|) in the parameter.  delta = 2^-21 * (131072 |A| + |B|) = e (1048576 |A| + 8 |B|) covers it:
+// the entry constant is lowered and the exit constant raised by delta, so the computed interval always contains
+// the exact one.  Nothing here decides a pixel: it only
 // has to keep every shape reachable that the exact tests would accept.
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct RayBox {
@@ -162,7 +165,9 @@ struct RayBox {
 __device__ __forceinline__ float safe_inverse(float d, float limit) {
     // A zero (or denormal) direction component would make A and B infinite and their sum NaN;
     // a huge finite slope keeps the slab semantics (inside: unbounded interval, outside: empty).
-    float inv = 1.0f / d;
+    // The hardware reciprocal (within one unit in the last place) instead of a division: culling only has to be
+    // conservative, and the slack on the slab constants covers it (make_axis).
+    float inv = __builtin_amdgcn_rcpf(d);
     return fminf(fmaxf(inv, -limit), limit);
 }
 
@@ -259,13 +264,13 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             // where the step leads, and what a pop would return from there
             const uint32_t next = both ? (swap ? r1 : r0) : (any ? (h0 ? r0 : r1) : below);
             const uint32_t under = both ? far_child : (any ? below : below2);
-            top += both ? 64 : (any ? 0 : -64);
             // a lane without a leaf in hand sets the one it has reached aside and goes on with what lies under it
             const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
             held = take ? next : held;
             cur = take ? under : next;
-            top -= take ? 64 : 0;
-            if (__builtin_amdgcn_ballot_w64(held == 0 && !(cur & REF_LEAF)) == 0) break;    // nobody is still looking for a first leaf
+            top = (uint32_t*)((char*)top + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));   // 256 bytes: one entry of every lane
+            // nobody is still looking for a first leaf: no lane with empty hands and an inner node before it (one compare per lane)
+            if (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) == 0) break;
         }
         if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf
             held = cur;
