@@ -239,8 +239,9 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = best->prim == NO_PRIM ? INF : prune_limit(best->t);
     // Entries 0 and 1 of every lane's stack hold REF_EMPTY: popping needs no emptiness test, and the two entries below
-    // the top can always be read.  `top` is the next free entry.
-    uint32_t* top = stack + 128;
+    // the top can always be read.  `low` points two entries below the next free one (low[128]), so that all three
+    // accesses of a step take non-negative offsets, which fit the immediate field of the LDS instructions.
+    uint32_t* low = stack;
     // All lanes descend through inner nodes until each has reached a leaf (or run out of nodes),
     // then all test their leaves together.  A lane that reaches its leaf early sets it aside and
     // keeps descending towards its next one instead of idling (it then tests both).
@@ -251,7 +252,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
         while (!(cur & REF_LEAF)) {
             const uint4* n = (const uint4*)((const char*)sc.nodes + (cur << 5));   // 32-byte pairs; a 32-bit offset keeps the address in one register
             const uint4 c0 = n[0], c1 = n[1];
-            uint32_t below = top[-64], below2 = top[-128];
+            uint32_t below = low[64], below2 = low[0];
             asm volatile("" : "+v"(below), "+v"(below2));       // keeps the reads here, under the node loads, instead of behind the box tests
             float t0, t1;
             bool h0 = slab(c0, rb, tlim, &t0);
@@ -260,7 +261,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             const uint32_t r0 = c0.w, r1 = c1.w;
             const bool both = h0 && h1, any = h0 || h1, swap = t1 < t0;
             const uint32_t far_child = swap ? r0 : r1;
-            if (both) *top = far_child;
+            if (both) low[128] = far_child;
             // where the step leads, and what a pop would return from there
             const uint32_t next = both ? (swap ? r1 : r0) : (any ? (h0 ? r0 : r1) : below);
             const uint32_t under = both ? far_child : (any ? below : below2);
@@ -268,17 +269,17 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
             held = take ? next : held;
             cur = take ? under : next;
-            top = (uint32_t*)((char*)top + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));   // 256 bytes: one entry of every lane
+            low = (uint32_t*)((char*)low + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));   // 256 bytes: one entry of every lane
             // nobody is still looking for a first leaf: no lane with empty hands and an inner node before it (one compare per lane)
             if (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) == 0) break;
         }
         if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf
             held = cur;
-            top -= 64; cur = *top;
+            low -= 64; cur = low[128];
         }
         while (held != 0) {
             uint32_t first = (held & ~REF_LEAF) >> 3, count = (held & 7u) + 1u;
-            uint32_t below = top[-64];
+            uint32_t below = low[64];
             asm volatile("" : "+v"(below));                     // read under the shape loads
             for (uint32_t k = 0; k < count; k++) {
                 const float4* p = sc.tree + 3 * (size_t)(first + k);
@@ -293,7 +294,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             held = 0;
             if ((cur & REF_LEAF) && cur != REF_EMPTY) {
                 held = cur;
-                top -= 64; cur = below;
+                low -= 64; cur = below;
             }
         }
         if (cur == REF_EMPTY) break;
@@ -322,12 +323,12 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
     if (cur == REF_EMPTY) return false;
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = point_light ? prune_limit(light_dist) : INF;
-    uint32_t* top = stack + 128;                        // as in closest_hit
+    uint32_t* low = stack;                              // as in closest_hit: the next free entry is low[128]
     while (cur != REF_EMPTY) {
         while (!(cur & REF_LEAF)) {
             const uint4* n = (const uint4*)((const char*)sc.nodes + (cur << 5));   // 32-byte pairs; a 32-bit offset keeps the address in one register
             const uint4 c0 = n[0], c1 = n[1];
-            uint32_t below = top[-64];
+            uint32_t below = low[64];
             asm volatile("" : "+v"(below));       // keeps the read here, under the node loads, instead of behind the box tests
             float t0, t1;
             bool h0 = slab(c0, rb, tlim, &t0);
@@ -335,20 +336,20 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
             if (COUNT) { cnt->nodes += 2; if (first_active_lane()) cnt->wave_node_iters++; }
             const uint32_t r0 = c0.w, r1 = c1.w;
             const bool both = h0 && h1;
-            if (both) *top = r1;
+            if (both) low[128] = r1;
             cur = h0 ? r0 : (h1 ? r1 : below);
-            top += both ? 64 : ((h0 || h1) ? 0 : -64);
+            low += both ? 64 : ((h0 || h1) ? 0 : -64);
         }
         if (cur != REF_EMPTY) {
             uint32_t first = (cur & ~REF_LEAF) >> 3, count = (cur & 7u) + 1u;
-            uint32_t below = top[-64];
+            uint32_t below = low[64];
             asm volatile("" : "+v"(below));       // read under the shape loads
             for (uint32_t k = 0; k < count; k++) {
                 const float4* p = sc.tree + 3 * (size_t)(first + k);
                 if (COUNT) { cnt->prims++; if (first_active_lane()) cnt->wave_prim_iters++; }
                 if (occludes(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
             }
-            top -= 64; cur = below;
+            low -= 64; cur = below;
         }
     }
     return false;
