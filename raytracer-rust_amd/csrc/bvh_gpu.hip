@@ -661,10 +661,16 @@ __global__ __launch_bounds__(256) void gather_records(const rtl::ShapeRec* __res
                                                       rtl::ShapeRec* __restrict__ out) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    // 48-byte records as three 16-byte words
+    // 48-byte records as three 16-byte words; triangles leave as {v0, v1 - v0, v2 - v0} (rtl::to_blob_form)
     const float4* src = (const float4*)(rec + order[p]);
     float4* dst = (float4*)(out + p);
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    const float4 q0 = src[0];
+    float4 q1 = src[1], q2 = src[2];
+    if ((__float_as_uint(q0.w) & 3u) == rtl::KIND_TRIANGLE) {
+        q1.x = q1.x - q0.x; q1.y = q1.y - q0.y; q1.z = q1.z - q0.z;
+        q2.x = q2.x - q0.x; q2.y = q2.y - q0.y; q2.z = q2.z - q0.z;
+    }
+    dst[0] = q0; dst[1] = q1; dst[2] = q2;
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }

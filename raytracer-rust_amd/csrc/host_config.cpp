@@ -542,7 +542,7 @@ struct CacheHeader {
     uint64_t header_hash;          // of the whole header block with this field zero: damage to the Config fields is noticed too
 };
 constexpr size_t CACHE_HEADER_BYTES = 4096;
-constexpr uint32_t CACHE_VERSION = 2;
+constexpr uint32_t CACHE_VERSION = 3;
 const char CACHE_MAGIC[8] = {'R', 'T', 'S', 'C', 'A', 'C', 'H', 'E'};
 static_assert(sizeof(CacheHeader) <= CACHE_HEADER_BYTES, "cache header must fit its block");
 

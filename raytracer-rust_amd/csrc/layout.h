@@ -21,8 +21,9 @@
 //                    less than two units: 0.002 % of the scene extent).  One 16-byte load per child.
 //   shape      48 B  three float4.  q0.w carries kind | material << 2, q1.w the shape's
 //                    position in the scene file (tie break), q2.w is spare.
-//                      triangle: q0.xyz = v0, q1.xyz = v1, q2.xyz = v2   (raw vertices: the
-//                                edges are recomputed per test, as shape.rs:149-150 does)
+//                      triangle: q0.xyz = v0, q1.xyz = v1 - v0, q2.xyz = v2 - v0   (the two edges every
+//                                test starts from, shape.rs:149-150, subtracted once in binary32 when the
+//                                blob is written: the same bits the per-test subtraction would give)
 //                      sphere:   q0.xyz = center, q1.x = radius
 //                      plane:    q0.xyz = point,  q2.xyz = unit normal
 //   material   32 B  {diffuse.rgb, shininess} {specular.rgb, 0}
@@ -68,11 +69,17 @@ RT_LAYOUT_FN uint32_t grid_code_above(float u) { return u <= 32768.0f ? (uint32_
 struct ShapeRec { float q0[3]; uint32_t kind_mat; float q1[3]; uint32_t order; float q2[3]; uint32_t spare; };
 static_assert(sizeof(ShapeRec) == 48, "shape record must be 48 bytes");
 
+// A record as the builders handle it (triangles with their three vertices) -> as the blob stores it.
+RT_LAYOUT_FN void to_blob_form(ShapeRec* r) {
+    if ((r->kind_mat & 3u) != KIND_TRIANGLE) return;
+    for (int k = 0; k < 3; k++) { r->q1[k] = r->q1[k] - r->q0[k]; r->q2[k] = r->q2[k] - r->q0[k]; }
+}
+
 struct MaterialRec { float diffuse[3]; float shininess; float specular[3]; float pad; };
 struct LightRec { float v[3]; float kind; float color[3]; float pad; };
 
 constexpr uint32_t BLOB_MAGIC = 0x52544231u;   // "RTB1"
-constexpr uint32_t BLOB_VERSION = 4;
+constexpr uint32_t BLOB_VERSION = 5;
 
 struct BlobHeader {
     uint32_t magic, version;

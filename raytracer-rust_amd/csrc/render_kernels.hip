@@ -84,9 +84,8 @@ __device__ __forceinline__ bool first_active_lane() { return (threadIdx.x & 63u)
 // ------------------------------------------------------------------ exact shape tests
 // Each returns whether the reference's test yields Some(..) and the distance it would carry.
 
-__device__ __forceinline__ bool test_triangle(V3 v0, V3 v1, V3 v2, V3 o, V3 d, float* t_out) {   // shape.rs:149-176
-    V3 e1 = vsub(v1, v0);
-    V3 e2 = vsub(v2, v0);
+// e1 = v1 - v0 and e2 = v2 - v0 (shape.rs:149-150) come ready-made from the shape record.
+__device__ __forceinline__ bool test_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float* t_out) {   // shape.rs:151-176
     V3 h = vcross(d, e2);
     float a = vdot(e1, h);
     if (fabsf(a) < 1e-6f) return false;
@@ -135,8 +134,7 @@ __device__ __forceinline__ bool test_shape(const float4 q0, const float4 q1, con
 __device__ __forceinline__ bool shape_back_face(const float4 q0, const float4 q1, const float4 q2, V3 d) {
     uint32_t kind = __float_as_uint(q0.w) & 3u;
     if (kind != KIND_TRIANGLE) return false;
-    V3 e1 = vsub(v3(q1), v3(q0)), e2 = vsub(v3(q2), v3(q0));
-    V3 n = vnormalize(vcross(e1, e2));
+    V3 n = vnormalize(vcross(v3(q1), v3(q2)));       // the record holds the edges
     return vdot(n, d) > 0.0f;
 }
 
@@ -430,8 +428,7 @@ __device__ __forceinline__ void render_pixel_tile(const DevScene& sc, const DevF
             V3 point = vadd(o, vscale(d, best.t));
             V3 normal; bool back = false;
             if (kind == KIND_TRIANGLE) {
-                V3 e1 = vsub(v3(q1), v3(q0)), e2 = vsub(v3(q2), v3(q0));
-                normal = vnormalize(vcross(e1, e2));
+                normal = vnormalize(vcross(v3(q1), v3(q2)));      // the record holds the edges
                 back = vdot(normal, d) > 0.0f;
             } else if (kind == KIND_SPHERE) {
                 normal = vnormalize(vsub(point, v3(q0)));

@@ -245,6 +245,7 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
         }
     }
     std::sort(out->list.begin(), out->list.end(), [](const rtl::ShapeRec& a, const rtl::ShapeRec& b) { return a.order < b.order; });
+    for (rtl::ShapeRec& r : out->list) rtl::to_blob_form(&r);      // nothing needs their boxes: straight into the form the blob keeps
 
     out->lights.resize(s.nlights);
     bool finite = true;
@@ -350,7 +351,7 @@ bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info
     std::memcpy(blob->data(), &h, sizeof(h));        // after the grid has been filled in
     rtl::ShapeRec* ts = (rtl::ShapeRec*)(blob->data() + h.off_tree_shapes);
 #pragma omp parallel for schedule(static) if (nt > 100000)
-    for (int64_t j = 0; j < (int64_t)nt; j++) ts[j] = parts.tree[bvh.order[(size_t)j]];
+    for (int64_t j = 0; j < (int64_t)nt; j++) { ts[j] = parts.tree[bvh.order[(size_t)j]]; rtl::to_blob_form(&ts[j]); }
     if (!list_shapes.empty()) std::memcpy(blob->data() + h.off_list_shapes, list_shapes.data(), list_shapes.size() * sizeof(rtl::ShapeRec));
     if (!mats.empty()) std::memcpy(blob->data() + h.off_materials, mats.data(), mats.size() * sizeof(rtl::MaterialRec));
     if (!parts.lights.empty()) std::memcpy(blob->data() + h.off_lights, parts.lights.data(), parts.lights.size() * sizeof(rtl::LightRec));

@@ -25,8 +25,10 @@ constexpr uint32_t TREE_DEPTH_LIMIT = 63;
 
 
 // The same scene split into the parts of a blob without a tree, for the GPU tree builder: shape
-// records of the tree shapes in input order (triangles, then spheres), the always-tested list in
-// file order, the material table, the lights, and the padding rule of the node boxes.
+// records of the tree shapes in input order (triangles, then spheres; triangles still with their three
+// vertices, which the builders take the boxes from: whoever writes them into a blob applies
+// rtl::to_blob_form), the always-tested list in file order and already in blob form, the material
+// table, the lights, and the padding rule of the node boxes.
 // use_tree is false for scenes so small that every shape goes to the list (then pack_scene is the way).
 // The whole job of the host path: split, tree build (bvh_build.cpp), blob.  Padding between the sections of the blob is zero.
 bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info* info, std::string* err);

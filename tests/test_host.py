@@ -336,7 +336,7 @@ HDR = struct.Struct("<IIQ5Q5II3IfI3f3f")
 def _read_blob(blob):
     (magic, ver, total, o_nodes, o_tree, o_list, o_mat, o_light, n_pairs, n_tree, n_list, n_mat, n_light, root,
      max_depth, max_leaf, n_leaves, sah, finite, gx, gy, gz, sx, sy, sz) = HDR.unpack_from(blob.tobytes()[:HDR.size])
-    assert magic == 0x52544231 and ver == 4 and total == len(blob)
+    assert magic == 0x52544231 and ver == 5 and total == len(blob)
     nodes = blob[o_nodes:o_nodes + 32 * n_pairs].view(np.uint32).reshape(n_pairs, 8)
     tree = blob[o_tree:o_tree + 48 * n_tree].view(np.uint32).reshape(n_tree, 12)
     lst = blob[o_list:o_list + 48 * n_list].view(np.uint32).reshape(n_list, 12)
@@ -362,9 +362,11 @@ def _check_tree(b):
 
     def shape_box(rec_u, rec_f):
         kind = rec_u[3] & 3
-        if kind == 1:
-            v = np.stack([rec_f[0:3], rec_f[4:7], rec_f[8:11]])
-            return v.min(0), v.max(0)
+        if kind == 1:         # a triangle is stored as v0 and its two edges; v0 + edge is the vertex to within one rounding
+            v0, e1, e2 = np.float64(rec_f[0:3]), np.float64(rec_f[4:7]), np.float64(rec_f[8:11])
+            v = np.stack([v0, v0 + e1, v0 + e2])
+            ulp = np.abs(v).max(0) * 2.0 ** -23
+            return v.min(0) + ulp, v.max(0) - ulp
         assert kind == 0
         c, r = rec_f[0:3], rec_f[4]
         return c - r, c + r
