@@ -49,33 +49,28 @@ inline uint32_t region_log2_for(uint64_t tiles) {
     return l;
 }
 
-// Two builds of the render kernel, chosen per launch by the size of the resident scene:
-//   4 wavefronts per SIMD   128 vector registers (no spills), 10 KiB of LDS per wavefront.  For scenes that live in the
-//                           caches (the 7 MB dragon): the kernel is then bound by the chain of dependent traversal
-//                           steps and by vector ALU issue, and spill traffic costs more than a fifth wavefront gains.
-//   5 wavefronts per SIMD   96 vector registers (a few dozen bytes per lane spilled outside the inner loops), 8 KiB of
-//                           LDS.  For scenes beyond the caches (the 641 MB mesh): memory latency dominates and the
-//                           fifth wavefront hides more of it than the spills cost (42.4 against 46.8 ms on the 8K mesh).
-// LDS of one wavefront: a traversal stack of one entry per tree level plus two sentinels (256 bytes per entry), and, when
-// they fit beside it, the records of the reflection levels (maxdepth - 1 levels of 1 KiB); a frame whose records do not
-// fit keeps them in a global array instead.
-#ifndef RT_HIGH_WAVES
-#define RT_HIGH_WAVES 5          // wavefronts per SIMD of the second build
+// The render kernel runs at RT_WAVES wavefronts per SIMD: 5, i.e. 96 vector registers (a few bytes per lane spilled
+// outside the inner loops) and 7.5 KiB of LDS per wavefront.  The kernel is bound by vector ALU issue and by the chain of
+// dependent traversal steps of each wavefront; a fifth wavefront hides more of the latter than its spills cost (4K dragon
+// 3.24 against 3.40 ms at four, 8K mesh 37 against 41 ms), a sixth (80 registers) spills inside the loops and loses.
+// LDS of one wavefront: a traversal stack of one entry per tree level plus two sentinels (256 bytes per entry), and behind
+// it the records of the first reflection levels (1 KiB per level), as many as fit; the records of deeper levels, which
+// fewer pixels reach, go to a global array.
+#ifndef RT_WAVES
+#define RT_WAVES 5
 #endif
-struct RenderPlan { int waves; bool fold_in_lds; };
-constexpr size_t RT_CACHE_RESIDENT_BYTES = 128u << 20;      // half the 256 MB memory-side cache
+// An even share of the 160 KiB of a compute unit less half a KiB: with 8 192 bytes per wavefront only four fit a SIMD
+// (measured: 7 680 bytes run at five, 8 192 at four).
+constexpr uint32_t RT_LDS_PER_WAVE = ((160u * 1024u / (4u * RT_WAVES)) & ~255u) - 512u;
+struct RenderPlan { uint32_t lds_levels; };          // reflection levels 0 .. lds_levels - 1 keep their records in LDS
 inline uint32_t rtk_stack_entries(int stack_depth) { return (uint32_t)(stack_depth < 6 ? 8 : stack_depth + 2); }     // two sentinels
-inline RenderPlan rtk_render_plan(size_t scene_bytes, int stack_depth, uint32_t maxdepth) {
+inline RenderPlan rtk_render_plan(int stack_depth, uint32_t maxdepth) {
     RenderPlan p;
-#if defined(RT_FORCE_WAVES)
-    p.waves = RT_FORCE_WAVES;
-#else
-    p.waves = scene_bytes > RT_CACHE_RESIDENT_BYTES ? 5 : 4;
-#endif
-    const uint64_t budget = p.waves == 4 ? 10240 : (RT_HIGH_WAVES == 5 ? 8192 : 6656), levels = maxdepth > 1 ? (uint64_t)maxdepth - 1u : 0u;
-    p.fold_in_lds = levels == 0 || (levels <= 8 && (uint64_t)rtk_stack_entries(stack_depth) * 256u + levels * 1024u <= budget);
+    const uint32_t levels = maxdepth > 1 ? maxdepth - 1u : 0u, stack_bytes = rtk_stack_entries(stack_depth) * 256u;
+    const uint32_t room = stack_bytes < RT_LDS_PER_WAVE ? (RT_LDS_PER_WAVE - stack_bytes) / 1024u : 0u;
+    p.lds_levels = levels < room ? levels : room;
 #ifdef RT_FOLD_GLOBAL
-    p.fold_in_lds = levels == 0;
+    p.lds_levels = 0;
 #endif
     return p;
 }

@@ -372,10 +372,11 @@ __device__ __forceinline__ uint32_t frame_row(const DevFrame& f, uint32_t r) {
 extern __shared__ uint32_t s_stack[];
 
 // FOLD_LDS: the {local colour, material} records of the reflection levels live in LDS behind the stacks
-// ([level][lane], 16 bytes each) instead of in the global `fold` array ([level][pixel]).
-template <bool COUNT, bool FOLD_LDS>
-__device__ __forceinline__ void render_pixel_tile(const DevScene& sc, const DevFrame& f, uint32_t* __restrict__ out, float4* __restrict__ fold,
-                                                   unsigned long long* __restrict__ counters, uint32_t stack_entries) {
+// ([level][lane], 16 bytes each), those of the deeper levels in the global `fold` array ([level - lds_levels][pixel]).
+template <bool COUNT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT_WAVES))) void render_kernel(DevScene sc, DevFrame f, uint32_t* __restrict__ out,
+                                                                                                        float4* __restrict__ fold, unsigned long long* __restrict__ counters,
+                                                                                                        uint32_t stack_entries, uint32_t lds_levels) {
     const uint32_t lane = threadIdx.x;
     float4* const fold_lds = (float4*)(s_stack + stack_entries * 64u) + lane;
     // Which 8x8 pixel tile this wavefront renders.  Workgroups are dealt round-robin over the 8
@@ -473,8 +474,9 @@ __device__ __forceinline__ void render_pixel_tile(const DevScene& sc, const DevF
             V3 local = vadd(acc, ambient);                                                       // raytracer.rs:181
             bool reflective = specular_color.x > 0.0f || specular_color.y > 0.0f || specular_color.z > 0.0f;
             if (!(reflective && depth + 1u < f.maxdepth)) { cur = local; break; }                // raytracer.rs:187
-            if (FOLD_LDS) fold_lds[depth * 64u] = make_float4(local.x, local.y, local.z, __uint_as_float(mat));
-            else fold[(size_t)depth * npix + pix] = make_float4(local.x, local.y, local.z, __uint_as_float(mat));
+            const float4 record = make_float4(local.x, local.y, local.z, __uint_as_float(mat));
+            if (depth < lds_levels) fold_lds[depth * 64u] = record;
+            else fold[(size_t)(depth - lds_levels) * npix + pix] = record;
             float k2 = 2.0f * vdot(d, normal);                                                   // raytracer.rs:188-190
             d = vsub(d, vscale(normal, k2));
             o = shadow_origin;
@@ -484,7 +486,7 @@ __device__ __forceinline__ void render_pixel_tile(const DevScene& sc, const DevF
         // Backward fold: final_k = local_k + specular_k (*) final_{k+1}                           raytracer.rs:194-195
         while (depth > 0) {
             depth--;
-            const float4 rec = FOLD_LDS ? fold_lds[depth * 64u] : fold[(size_t)depth * npix + pix];
+            const float4 rec = depth < lds_levels ? fold_lds[depth * 64u] : fold[(size_t)(depth - lds_levels) * npix + pix];
             const float4 m1 = sc.mats[2 * (size_t)__float_as_uint(rec.w) + 1];
             cur = vadd(v3(rec), vcmul(v3(m1), cur));
         }
@@ -499,20 +501,6 @@ __device__ __forceinline__ void render_pixel_tile(const DevScene& sc, const DevF
             if (lane == 0 && s) atomicAdd(&counters[k], s);
         }
     }
-}
-
-// The two builds (device_types.h: RenderPlan): the same code under a register budget of 128 and of 96.
-template <bool COUNT, bool FOLD_LDS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_kernel(DevScene sc, DevFrame f, uint32_t* __restrict__ out,
-                                                                                              float4* __restrict__ fold, unsigned long long* __restrict__ counters,
-                                                                                              uint32_t stack_entries) {
-    render_pixel_tile<COUNT, FOLD_LDS>(sc, f, out, fold, counters, stack_entries);
-}
-template <bool COUNT, bool FOLD_LDS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_HIGH_WAVES, RT_HIGH_WAVES))) void render_kernel_5(DevScene sc, DevFrame f, uint32_t* __restrict__ out,
-                                                                                                float4* __restrict__ fold, unsigned long long* __restrict__ counters,
-                                                                                                uint32_t stack_entries) {
-    render_pixel_tile<COUNT, FOLD_LDS>(sc, f, out, fold, counters, stack_entries);
 }
 
 // Regions by decreasing measured cost (bitonic sort of one workgroup in LDS; keys cost << 32 | ~index so that
@@ -565,21 +553,15 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     const uint32_t entries = rtk_stack_entries(stack_depth);
     if (entries > 65) return hipErrorInvalidValue;
     size_t lds_bytes = (size_t)entries * 64 * sizeof(uint32_t);
-    const bool fold_lds = plan.fold_in_lds;
-    if (fold_lds && f->maxdepth > 1) lds_bytes += (size_t)(f->maxdepth - 1u) * 64 * sizeof(float4);
-    else if (f->maxdepth > 1 && !d_fold) return hipErrorInvalidValue;
+    const uint32_t levels = f->maxdepth > 1 ? f->maxdepth - 1u : 0u;
+    if (plan.lds_levels > levels) return hipErrorInvalidValue;
+    lds_bytes += (size_t)plan.lds_levels * 64 * sizeof(float4);
+    if (lds_bytes > 64u * 1024u || (plan.lds_levels < levels && !d_fold)) return hipErrorInvalidValue;
 #ifdef RT_DIAG_LDS_PAD
     { static const char* pad = getenv("RT_DIAG_LDS_PAD"); if (pad) lds_bytes = std::max(lds_bytes, (size_t)atoi(pad)); }   // occupancy experiments (scripts/ab_occ.sh)
 #endif
-#define RT_LAUNCH(KERNEL, C, F) hipLaunchKernelGGL((KERNEL<C, F>), grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries)
-    if (plan.waves == 5) {
-        if (count) { if (fold_lds) RT_LAUNCH(render_kernel_5, true, true); else RT_LAUNCH(render_kernel_5, true, false); }
-        else { if (fold_lds) RT_LAUNCH(render_kernel_5, false, true); else RT_LAUNCH(render_kernel_5, false, false); }
-    } else {
-        if (count) { if (fold_lds) RT_LAUNCH(render_kernel, true, true); else RT_LAUNCH(render_kernel, true, false); }
-        else { if (fold_lds) RT_LAUNCH(render_kernel, false, true); else RT_LAUNCH(render_kernel, false, false); }
-    }
-#undef RT_LAUNCH
+    if (count) hipLaunchKernelGGL(render_kernel<true>, grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries, plan.lds_levels);
+    else hipLaunchKernelGGL(render_kernel<false>, grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries, plan.lds_levels);
     return hipGetLastError();
 }
 

@@ -173,7 +173,7 @@ int check_frame(const rt_frame* f) {
     return 0;
 }
 
-// Global array for the records of the reflection levels, for frames whose records do not fit in LDS.
+// Global array for the records of the reflection levels that do not fit in LDS.
 int ensure_fold(Lane& lane, size_t npix, size_t levels) {
     const size_t limit = (200ull << 30) / sizeof(float4);
     if (levels != 0 && npix > limit / levels) return fail("maxdepth x pixels needs more than 200 GiB of fold records");
@@ -248,8 +248,8 @@ int enqueue_shard(int d, const rt_frame* frame, uint32_t shard, uint32_t nshards
     if (!d_out) return fail("output buffer is NULL");
     size_t npix = (size_t)local_rows * frame->width;
     uint32_t levels = frame->maxdepth > 1 ? frame->maxdepth - 1 : 0;
-    const RenderPlan plan = rtk_render_plan(g.devs[d].blob_bytes, (int)g.hdr.max_depth, frame->maxdepth);
-    if (!plan.fold_in_lds && ensure_fold(lane, npix, levels)) return 1;
+    const RenderPlan plan = rtk_render_plan((int)g.hdr.max_depth, frame->maxdepth);
+    if (plan.lds_levels < levels && ensure_fold(lane, npix, levels - plan.lds_levels)) return 1;
     if (count_work) HIP_TRY(hipMemsetAsync(lane.d_counters, 0, 8 * sizeof(unsigned long long), lane.stream));
     if (plan_regions(lane, *frame, &f)) return 1;
     if (timed) HIP_TRY(hipEventRecord(lane.ev0, lane.stream));
