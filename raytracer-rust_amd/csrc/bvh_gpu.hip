@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void compact_pairs(uint32_t slots, const rtl::
     if (s >= slots || !used[s]) return;
     rtl::QuantPair p = in[s];
     for (int k = 0; k < 2; k++)
-        if (!(p.c[k].ref & rtl::REF_LEAF)) p.c[k].ref = p.c[k].ref < slots ? new_index[p.c[k].ref] : rtl::REF_EMPTY;
+        if (!(p.c[k].ref & rtl::REF_LEAF)) p.c[k].ref = p.c[k].ref < slots ? rtl::inner_ref(new_index[p.c[k].ref]) : rtl::REF_EMPTY;
     out[new_index[s]] = p;
 }
 
@@ -695,7 +695,7 @@ struct DeviceBuffers {               // everything the build needs besides the b
 
 BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltScene* out, std::string* err) {
     const uint32_t n = in.n_tree;
-    if (n < 2 || n > rtl::MAX_TREE_SHAPES) { *err = "GPU tree build needs between 2 and 2^27 shapes"; return BUILD_FAILED; }
+    if (n < 2 || n > rtl::MAX_TREE_SHAPES) { *err = "GPU tree build needs between 2 and 2^26 shapes"; return BUILD_FAILED; }
     const uint32_t blocks_n = (n + 255) / 256;
     DeviceBuffers mem;
     rtl::ShapeRec* d_rec; float4 *d_lo, *d_hi, *d_slo, *d_shi; Bounds* d_bounds;
@@ -849,7 +849,7 @@ BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltSc
     // 6. the blob
     h.magic = rtl::BLOB_MAGIC; h.version = rtl::BLOB_VERSION;
     h.n_pairs = n_pairs; h.n_tree_shapes = n; h.n_list_shapes = in.n_list; h.n_materials = in.n_mats; h.n_lights = in.n_lights;
-    h.root_ref = root_ref;
+    h.root_ref = rtl::inner_ref(root_ref);
     h.max_depth = stats.max_depth; h.finite_shading = in.finite_shading;
     h.n_leaves = stats.n_leaves; h.max_leaf = stats.max_leaf;
     h.sah_cost = (float)((double)stats.cost_micro * 1e-6);

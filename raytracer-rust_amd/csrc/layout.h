@@ -38,14 +38,17 @@ namespace rtl {
 
 constexpr uint32_t KIND_SPHERE = 0, KIND_TRIANGLE = 1, KIND_PLANE = 2;
 
-// Child reference.  Inner: index of a node pair (bit 31 clear).  Leaf: bit 31 set,
-// bits 30..3 = first shape of the leaf in the tree-shape array, bits 2..0 = count - 1.
+// Child reference.  Inner (bit 31 clear): the node pair's byte offset in the node array, 32 x its index, so that a
+// traversal step adds it to the base address as it is (the builders work with plain indices; inner_ref converts).
+// Leaf: bit 31 set, bits 30..3 = first shape of the leaf in the tree-shape array, bits 2..0 = count - 1.
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_EMPTY = 0xFFFFFFFFu;   // never produced for a real leaf (would need first = 2^28 - 1)
 constexpr uint32_t MAX_LEAF = 8;
-constexpr uint32_t MAX_TREE_SHAPES = 1u << 27;   // fewer node pairs than 2^27: the kernels address the node array with 32-bit byte offsets
+constexpr uint32_t MAX_TREE_SHAPES = 1u << 26;   // fewer node pairs than 2^26: their byte offsets leave bit 31 of a reference free
 
 inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return REF_LEAF | (first << 3) | (count - 1); }
+// A builder's reference (pair index or leaf) -> the blob's.
+constexpr uint32_t inner_ref(uint32_t builder_ref) { return (builder_ref & REF_LEAF) ? builder_ref : builder_ref << 5; }
 
 // Builder-side record (full precision), quantised by scene_pack.cpp into QuantPair.
 struct ChildBox { float lo[3]; uint32_t ref; float hi[3]; uint32_t count; };
@@ -79,7 +82,7 @@ struct MaterialRec { float diffuse[3]; float shininess; float specular[3]; float
 struct LightRec { float v[3]; float kind; float color[3]; float pad; };
 
 constexpr uint32_t BLOB_MAGIC = 0x52544231u;   // "RTB1"
-constexpr uint32_t BLOB_VERSION = 5;
+constexpr uint32_t BLOB_VERSION = 6;
 
 struct BlobHeader {
     uint32_t magic, version;

@@ -248,7 +248,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
     uint32_t held = 0;                                  // leaf set aside (leaf references are never 0)
     for (;;) {
         while (!(cur & REF_LEAF)) {
-            const uint4* n = (const uint4*)((const char*)sc.nodes + (cur << 5));   // 32-byte pairs; a 32-bit offset keeps the address in one register
+            const uint4* n = (const uint4*)((const char*)sc.nodes + cur);   // an inner reference is the pair's byte offset; 32 bits keep the address in one register
             const uint4 c0 = n[0], c1 = n[1];
             uint32_t below = low[64], below2 = low[0];
             asm volatile("" : "+v"(below), "+v"(below2));       // keeps the reads here, under the node loads, instead of behind the box tests
@@ -324,7 +324,7 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
     uint32_t* low = stack;                              // as in closest_hit: the next free entry is low[128]
     while (cur != REF_EMPTY) {
         while (!(cur & REF_LEAF)) {
-            const uint4* n = (const uint4*)((const char*)sc.nodes + (cur << 5));   // 32-byte pairs; a 32-bit offset keeps the address in one register
+            const uint4* n = (const uint4*)((const char*)sc.nodes + cur);   // an inner reference is the pair's byte offset; 32 bits keep the address in one register
             const uint4 c0 = n[0], c1 = n[1];
             uint32_t below = low[64];
             asm volatile("" : "+v"(below));       // keeps the read here, under the node loads, instead of behind the box tests

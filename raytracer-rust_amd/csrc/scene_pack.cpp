@@ -64,13 +64,13 @@ bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err) {
         *err = "scene blob: section outside the buffer";
         return false;
     }
-    if (h.n_pairs >= (1u << 27)) { *err = "scene blob: too many node pairs for 32-bit offsets"; return false; }
+    if (h.n_pairs >= (1u << 26)) { *err = "scene blob: too many node pairs for 31-bit offsets"; return false; }
     if (h.max_depth > TREE_DEPTH_LIMIT) { *err = "scene blob: tree deeper than the traversal stack"; return false; }
     if (h.root_ref != rtl::REF_EMPTY) {
         if (h.root_ref & rtl::REF_LEAF) {
             uint32_t first = (h.root_ref & ~rtl::REF_LEAF) >> 3, cnt = (h.root_ref & 7u) + 1u;
             if ((uint64_t)first + cnt > h.n_tree_shapes) { *err = "scene blob: root leaf outside the shape array"; return false; }
-        } else if (h.root_ref >= h.n_pairs) { *err = "scene blob: root outside the node array"; return false; }
+        } else if ((h.root_ref & 31u) || (h.root_ref >> 5) >= h.n_pairs) { *err = "scene blob: root outside the node array"; return false; }
     }
     return true;
 }
@@ -103,7 +103,7 @@ bool validate_blob(const uint8_t* blob, size_t bytes, std::string* err) {
     const rtl::QuantPair* pairs = (const rtl::QuantPair*)(blob + h.off_nodes);
     std::vector<uint8_t> seen(h.n_pairs, 0);
     std::vector<std::pair<uint32_t, uint32_t>> stack;   // pair index, depth
-    stack.push_back({h.root_ref, 1});
+    stack.push_back({h.root_ref >> 5, 1});
     uint64_t reached = 0;
     while (!stack.empty()) {
         auto [idx, depth] = stack.back(); stack.pop_back();
@@ -117,8 +117,8 @@ bool validate_blob(const uint8_t* blob, size_t bytes, std::string* err) {
                 uint32_t first = (ref & ~rtl::REF_LEAF) >> 3, cnt = (ref & 7u) + 1u;
                 if ((uint64_t)first + cnt > h.n_tree_shapes) { *err = "scene blob: leaf outside the shape array"; return false; }
             } else {
-                if (ref >= h.n_pairs) { *err = "scene blob: child outside the node array"; return false; }
-                stack.push_back({ref, depth + 1});
+                if ((ref & 31u) || (ref >> 5) >= h.n_pairs) { *err = "scene blob: child outside the node array"; return false; }
+                stack.push_back({ref >> 5, depth + 1});
             }
         }
     }
@@ -296,7 +296,7 @@ bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info
     h.magic = rtl::BLOB_MAGIC; h.version = rtl::BLOB_VERSION;
     h.n_pairs = (uint32_t)bvh.pairs.size(); h.n_tree_shapes = (uint32_t)nt; h.n_list_shapes = (uint32_t)list_shapes.size();
     h.n_materials = (uint32_t)mats.size(); h.n_lights = s.nlights;
-    h.root_ref = bvh.root_ref; h.max_depth = bvh.max_depth; h.max_leaf = bvh.max_leaf; h.n_leaves = bvh.n_leaves; h.sah_cost = (float)bvh.sah_cost;
+    h.root_ref = rtl::inner_ref(bvh.root_ref); h.max_depth = bvh.max_depth; h.max_leaf = bvh.max_leaf; h.n_leaves = bvh.n_leaves; h.sah_cost = (float)bvh.sah_cost;
     size_t off = sizeof(rtl::BlobHeader);
     h.off_nodes = off; off = align256(off + (size_t)h.n_pairs * sizeof(rtl::QuantPair));
     h.off_tree_shapes = off; off = align256(off + nt * sizeof(rtl::ShapeRec));
@@ -343,7 +343,7 @@ bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info
                     if (o + (double)rtl::grid_units(ql) * sc > (double)b.lo[k] || o + (double)rtl::grid_units(qh) * sc < (double)b.hi[k]) ok = false;
                     qp[i].c[c].q[k][0] = (uint16_t)ql; qp[i].c[c].q[k][1] = (uint16_t)qh;
                 }
-                qp[i].c[c].ref = b.ref;
+                qp[i].c[c].ref = rtl::inner_ref(b.ref);
             }
         }
         if (!ok) { *err = "internal: a node box does not fit the quantisation grid"; return false; }

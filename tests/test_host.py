@@ -336,7 +336,7 @@ HDR = struct.Struct("<IIQ5Q5II3IfI3f3f")
 def _read_blob(blob):
     (magic, ver, total, o_nodes, o_tree, o_list, o_mat, o_light, n_pairs, n_tree, n_list, n_mat, n_light, root,
      max_depth, max_leaf, n_leaves, sah, finite, gx, gy, gz, sx, sy, sz) = HDR.unpack_from(blob.tobytes()[:HDR.size])
-    assert magic == 0x52544231 and ver == 5 and total == len(blob)
+    assert magic == 0x52544231 and ver == 6 and total == len(blob)
     nodes = blob[o_nodes:o_nodes + 32 * n_pairs].view(np.uint32).reshape(n_pairs, 8)
     tree = blob[o_tree:o_tree + 48 * n_tree].view(np.uint32).reshape(n_tree, 12)
     lst = blob[o_list:o_list + 48 * n_list].view(np.uint32).reshape(n_list, 12)
@@ -376,6 +376,9 @@ def _check_tree(b):
         ref, depth, lo, hi = stack.pop()
         if ref == 0xFFFFFFFF:
             continue
+        if not ref & 0x80000000:          # an inner reference is the byte offset of a 32-byte pair
+            assert ref % 32 == 0
+            ref //= 32
         if ref & 0x80000000:
             first, cnt = (ref & 0x7FFFFFFF) >> 3, (ref & 7) + 1
             leaves += 1
@@ -551,6 +554,7 @@ def test_builder_output_passes_the_blob_check():
 
 @pytest.mark.parametrize("damage,msg", [
     ("child_out_of_range", "child outside the node array"),
+    ("child_misaligned", "child outside the node array"),
     ("cycle", "node pair referenced twice"),
     ("leaf_out_of_range", "leaf outside the shape array"),
     ("material", "unknown kind or material"),
@@ -565,7 +569,9 @@ def test_damaged_blobs_are_rejected_before_they_reach_a_gpu(damage, msg):
     nodes = b["nodes"]                       # views into `blob`: [lo/hi words x3, ref] per child
     inner = [i for i in range(len(nodes)) if not (nodes[i, 3] & 0x80000000)]
     if damage == "child_out_of_range":
-        nodes[inner[0], 3] = len(nodes) + 5
+        nodes[inner[0], 3] = 32 * (len(nodes) + 5)
+    elif damage == "child_misaligned":
+        nodes[inner[0], 3] = nodes[inner[0], 3] + 16
     elif damage == "cycle":
         nodes[inner[5], 3] = b["root"]
     elif damage == "leaf_out_of_range":
