@@ -281,7 +281,7 @@ def main():
     # Kernel-only duration (events bracketing just the kernel; the loop above brackets kernel + gather + reassembly),
     # the first frame of a freshly uploaded scene (no tile order from a previous launch yet), and the frame delivered to
     # host memory (the raytracer.rs:40 contract).
-    kernel_ms, cold_ms, host_ms = [], None, None
+    kernel_ms, cold_ms, host_ms, seeded_ms = [], None, None, None
     if mode == "ranks":
         for _ in range(min(args.steps, 10)):
             kernel_ms.append(rt.render_tiles(frame, rank, world, target.data_ptr(), want_stats=True)["kernel_ms"])
@@ -297,6 +297,12 @@ def main():
         assert np.array_equal(host_frame, frame_host), "rt_render and rt_render_frame disagree"
         rt.upload_scene(scene, gpu_build=gpu_build)                       # a new resident scene: the tile order starts from scratch
         cold_ms = rt.render_frame(frame, want_stats=True)[1]["kernel_ms"]
+        # ... and the first frame of a later run that kept the tile costs of this one beside its scene cache
+        saved = [rt.tile_costs_export(frame, gpu) for gpu in range(rt.device_count())]
+        rt.upload_scene(scene, gpu_build=gpu_build)
+        for gpu, costs in enumerate(saved):
+            rt.tile_costs_import(frame, costs, gpu)
+        seeded_ms = rt.render_frame(frame, want_stats=True)[1]["kernel_ms"]
     step_ms_events = [a.elapsed_time(b) for a, b in ev] if drives_gpus else []
 
     if rank == 0:
@@ -352,6 +358,7 @@ def main():
             "scene_upload_s": upload_s,
             "step_ms_hip_events_mean": float(np.mean(step_ms_events)),
             "cold_first_frame_ms": cold_ms,
+            "first_frame_with_saved_tile_costs_ms": seeded_ms,
             "rt_render_ms": host_ms,
             "frame_checksum": checksum,
             "roofline": roofline,

@@ -94,6 +94,9 @@ _SIGNATURES = {
     "rt_compare_frames": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]),
     "rt_compare_frames_noalloc": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rt_pack_rgb": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rt_tile_costs_count": (C.c_int, [C.POINTER(rt_frame), C.c_int, C.POINTER(C.c_uint32)]),
+    "rt_tile_costs_export": (C.c_int, [C.POINTER(rt_frame), C.c_int, C.c_void_p, C.c_uint32]),
+    "rt_tile_costs_import": (C.c_int, [C.POINTER(rt_frame), C.c_int, C.c_void_p, C.c_uint32]),
     "rt_select_lane": (C.c_int, [C.c_int]),
     "rt_stream": (C.c_void_p, []),
     "rt_synchronize": (C.c_int, []),
@@ -550,6 +553,64 @@ def stream():
     return lib().rt_stream()
 
 
+def tile_costs_count(frame, gpu=0):
+    """Number of tile regions whose cost a launch of `frame` on GPU `gpu` measures (0: too small a frame to be ordered)."""
+    n = C.c_uint32(0)
+    _check(lib().rt_tile_costs_count(C.byref(frame), int(gpu), C.byref(n)))
+    return n.value
+
+
+def tile_costs_export(frame, gpu=0):
+    """Costs measured by the last launch of `frame` on the current lane (uint32 per region)."""
+    costs = np.zeros(tile_costs_count(frame, gpu), dtype=np.uint32)
+    _check(lib().rt_tile_costs_export(C.byref(frame), int(gpu), costs.ctypes.data, len(costs)))
+    return costs
+
+
+def tile_costs_import(frame, costs, gpu=0):
+    """Orders the next launch of `frame` on the current lane by costs saved from an earlier one."""
+    costs = np.ascontiguousarray(costs, dtype=np.uint32)
+    _check(lib().rt_tile_costs_import(C.byref(frame), int(gpu), costs.ctypes.data, len(costs)))
+
+
+TILE_FILE_MAGIC = 0x31545452      # "RTT1"
+
+
+def save_tile_costs(path, frame):
+    """Writes the costs of the last launch of `frame` on every GPU the library drives to `path`:
+    [magic, bytes of the frame, GPUs, then per GPU its count and its costs], all uint32."""
+    words = [np.uint32([TILE_FILE_MAGIC, C.sizeof(frame)]), np.frombuffer(bytes(frame), dtype=np.uint8).astype(np.uint32), np.uint32([device_count()])]
+    for gpu in range(device_count()):
+        costs = tile_costs_export(frame, gpu)
+        words += [np.uint32([len(costs)]), costs]
+    tmp = f"{path}.{os.getpid()}.tmp"
+    np.concatenate(words).tofile(tmp)
+    os.replace(tmp, path)
+
+
+def load_tile_costs(path, frame):
+    """Hands the costs in `path` to the library if they were measured for this very frame on as many GPUs;
+    returns whether it did.  Anything else in the file is ignored: the costs only order the work."""
+    try:
+        w = np.fromfile(path, dtype=np.uint32)
+    except OSError:
+        return False
+    nb = C.sizeof(frame)
+    if len(w) < 3 + nb or w[0] != TILE_FILE_MAGIC or w[1] != nb or w[2 + nb] != device_count():
+        return False
+    if bytes(w[2:2 + nb].astype(np.uint8)) != bytes(frame):
+        return False
+    at, per_gpu = 3 + nb, []
+    for gpu in range(device_count()):
+        if at >= len(w) or at + 1 + int(w[at]) > len(w) or int(w[at]) != tile_costs_count(frame, gpu):
+            return False
+        per_gpu.append(w[at + 1:at + 1 + int(w[at])])
+        at += 1 + int(w[at])
+    for gpu, costs in enumerate(per_gpu):
+        tile_costs_import(frame, costs, gpu)
+    return True
+
+
 GPU_BUILD_FROM = 200_000      # shapes from which from_scene_file builds the tree on the GPU unless told otherwise
 
 class RayTracer:
@@ -564,6 +625,7 @@ class RayTracer:
         self.bvh_info = upload_scene(self._scene, gpu_build=gpu_build)          # RayTracer::new builds the tree (raytracer.rs:32)
         self._token = _resident_token
         self.last_stats = None
+        self._tiles_path, self._tiles_token = None, None
 
     @classmethod
     def new(cls, config):
@@ -575,13 +637,16 @@ class RayTracer:
         builds the tree and writes `cache_path` (default: path + ".rtcache"); later starts map the
         cache and upload it, as long as the scene file is unchanged.  gpu_build: where the tree is built
         on the first start (None: on the GPU from GPU_BUILD_FROM shapes on, where the host builder takes
-        longer than everything else put together; the frame does not depend on it)."""
+        longer than everything else put together; the frame does not depend on it).
+        The costs of the tile regions measured by the first frame go to cache_path + ".tiles", and the first frame of a
+        later start is handed out in that order (a one-frame run like main.rs:11-15 otherwise never sees an ordered launch)."""
         if _bound_device is None:
             init(0 if device is None else device)
         cache_path = cache_path or (os.fspath(path) + ".rtcache")
         self = cls.__new__(cls)
         self.last_stats = None
         self._cache_path, self._gpu_build = cache_path, False
+        self._tiles_path, self._tiles_token = cache_path + ".tiles", None
         try:
             cache = SceneCache(cache_path)
         except RtError:
@@ -623,7 +688,18 @@ class RayTracer:
 
     def render(self, count_work=False):
         self._make_resident()
-        pixels, self.last_stats = render(self.config.frame(), count_work=count_work)
+        frame = self.config.frame()
+        fresh = self._tiles_path is not None and self._tiles_token != _resident_token     # first frame since this scene became resident
+        if fresh:
+            load_tile_costs(self._tiles_path, frame)
+        pixels, self.last_stats = render(frame, count_work=count_work)
+        if fresh:                                              # (also when the order came from the file: every start refines it)
+            self._tiles_token = _resident_token
+            if tile_costs_count(frame) > 0:
+                try:
+                    save_tile_costs(self._tiles_path, frame)
+                except OSError:
+                    pass                                       # a read-only directory: the next start orders nothing, as this one
         return Image(pixels.shape[1], pixels.shape[0], pixels)
 
     def get_output_path(self):

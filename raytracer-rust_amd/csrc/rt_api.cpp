@@ -193,26 +193,45 @@ int ensure_fold(Lane& lane, size_t npix, size_t levels) {
 // one-workgroup sort behind the kernel turns that into the order in which the next launch of the same frame
 // geometry hands its regions out: slowest first, cheap ones last to fill the end.  The first launch of a
 // geometry uses raster order.  Only the order of the work changes, never a pixel.
-int plan_regions(Lane& lane, const rt_frame& fr, DevFrame* f) {
-    const uint32_t tiles_x = (f->width + 7u) >> 3, tiles_y = (f->local_rows + 7u) >> 3;
-    f->region_log2 = region_log2_for((uint64_t)tiles_x * tiles_y);
-    f->regions_x = 0; f->n_regions = 0; f->region_order = nullptr; f->region_cost = nullptr;
-    if (f->region_log2 == 0) return 0;
-    const uint32_t side = 1u << f->region_log2;
-    const uint32_t rx = (tiles_x + side - 1) / side, ry = (tiles_y + side - 1) / side;
-    f->regions_x = rx; f->n_regions = rx * ry;
-    if (f->n_regions > MAX_SORTED_REGIONS) return 0;          // (frames beyond 200 megapixels: raster order of regions)
+// Regions of a launch of local_rows rows of `width` pixels: side of a region in tiles as a power of two (0: the launch is
+// too small to be ordered) and how many regions there are across and down.
+struct RegionGrid { uint32_t log2, nx, ny; };
+RegionGrid region_grid(uint32_t width, uint32_t local_rows) {
+    const uint32_t tiles_x = (width + 7u) >> 3, tiles_y = (local_rows + 7u) >> 3;
+    RegionGrid r{region_log2_for((uint64_t)tiles_x * tiles_y), 0u, 0u};
+    if (r.log2 == 0) return r;
+    const uint32_t side = 1u << r.log2;
+    r.nx = (tiles_x + side - 1) / side; r.ny = (tiles_y + side - 1) / side;
+    return r;
+}
+
+RegionKey region_key(const rt_frame& fr, uint32_t shard, uint32_t nshards, uint32_t tile_rows) {
     RegionKey key{};
     key.width = fr.width; key.height = fr.height;
-    key.shard = f->shard; key.nshards = f->nshards; key.tile_rows = f->tile_rows; key.scene = g.scene_generation;
+    key.shard = shard; key.nshards = nshards; key.tile_rows = tile_rows; key.scene = g.scene_generation;
+    return key;
+}
+
+int reserve_regions(Lane& lane, uint32_t n_regions) {
+    if (n_regions <= lane.region_cap) return 0;
+    if (lane.d_region_order) { (void)hipFree(lane.d_region_order); lane.d_region_order = nullptr; lane.region_cap = 0; }
+    if (lane.d_region_cost) { (void)hipFree(lane.d_region_cost); lane.d_region_cost = nullptr; }
+    HIP_TRY(hipMalloc((void**)&lane.d_region_order, (size_t)n_regions * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&lane.d_region_cost, (size_t)n_regions * sizeof(uint32_t)));
+    lane.region_cap = n_regions;
+    return 0;
+}
+
+int plan_regions(Lane& lane, const rt_frame& fr, DevFrame* f) {
+    const RegionGrid grid = region_grid(f->width, f->local_rows);
+    f->region_log2 = grid.log2;
+    f->regions_x = 0; f->n_regions = 0; f->region_order = nullptr; f->region_cost = nullptr;
+    if (f->region_log2 == 0) return 0;
+    f->regions_x = grid.nx; f->n_regions = grid.nx * grid.ny;
+    if (f->n_regions > MAX_SORTED_REGIONS) return 0;          // (frames beyond 200 megapixels: raster order of regions)
+    const RegionKey key = region_key(fr, f->shard, f->nshards, f->tile_rows);
     if (!lane.region_key_valid || std::memcmp(&key, &lane.region_key, sizeof(key)) != 0) {
-        if (f->n_regions > lane.region_cap) {
-            if (lane.d_region_order) { (void)hipFree(lane.d_region_order); lane.d_region_order = nullptr; lane.region_cap = 0; }
-            if (lane.d_region_cost) { (void)hipFree(lane.d_region_cost); lane.d_region_cost = nullptr; }
-            HIP_TRY(hipMalloc((void**)&lane.d_region_order, (size_t)f->n_regions * sizeof(uint32_t)));
-            HIP_TRY(hipMalloc((void**)&lane.d_region_cost, (size_t)f->n_regions * sizeof(uint32_t)));
-            lane.region_cap = f->n_regions;
-        }
+        if (reserve_regions(lane, f->n_regions)) return 1;
         // All costs equal: the sort leaves the regions in index order.
         HIP_TRY(hipMemsetAsync(lane.d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), lane.stream));
         HIP_TRY(rtk_launch_sort_regions(lane.d_region_cost, f->n_regions, lane.d_region_order, lane.stream));
@@ -221,6 +240,21 @@ int plan_regions(Lane& lane, const rt_frame& fr, DevFrame* f) {
     HIP_TRY(hipMemsetAsync(lane.d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), lane.stream));
     f->region_order = lane.d_region_order;
     f->region_cost = lane.d_region_cost;
+    return 0;
+}
+
+// What rt_tile_costs_* address: the launch of `frame` that rt_render / rt_render_frame make on GPU `gpu`.
+int tile_cost_target(const rt_frame* frame, int gpu, RegionKey* key, uint32_t* n_regions) {
+    if (!g.inited) return fail("rt_init has not been called");
+    if (!g.have_scene) return fail("no scene uploaded");
+    if (check_frame(frame)) return 1;
+    if (gpu < 0 || gpu >= g.ndev) return fail("rt_tile_costs: no such GPU");
+    const uint32_t nshards = g.have_comm ? (uint32_t)g.ndev : 1u;
+    const uint32_t local_rows = rt_shard_rows(frame->height, (uint32_t)gpu, nshards, RT_TILE_ROWS);
+    const RegionGrid grid = region_grid(frame->width, local_rows);
+    const uint32_t n = grid.log2 == 0 ? 0u : grid.nx * grid.ny;
+    *n_regions = n > MAX_SORTED_REGIONS ? 0u : n;
+    *key = region_key(*frame, (uint32_t)gpu, nshards, RT_TILE_ROWS);
     return 0;
 }
 
@@ -601,6 +635,45 @@ int rt_pack_rgb(const uint32_t* d_pixels, uint32_t width, uint32_t height, uint8
     if (use(0)) return 1;
     HIP_TRY(rtk_launch_pack_rgb(d_pixels, (size_t)width * height, d_rgb, cur().stream));
     return 0;
+}
+
+int rt_tile_costs_count(const rt_frame* frame, int gpu, uint32_t* count) {
+    RegionKey key; uint32_t n = 0;
+    if (!count) return fail("rt_tile_costs_count: count is NULL");
+    if (tile_cost_target(frame, gpu, &key, &n)) return 1;
+    *count = n;
+    return 0;
+}
+
+int rt_tile_costs_export(const rt_frame* frame, int gpu, uint32_t* costs, uint32_t count) {
+    RegionKey key; uint32_t n = 0;
+    if (tile_cost_target(frame, gpu, &key, &n)) return 1;
+    if (count != n) return fail("rt_tile_costs_export: count differs from rt_tile_costs_count");
+    if (n == 0) return 0;
+    if (!costs) return fail("rt_tile_costs_export: costs is NULL");
+    if (use(gpu)) return 1;
+    Lane& lane = cur(gpu);
+    if (!lane.region_key_valid || std::memcmp(&key, &lane.region_key, sizeof(key)) != 0)
+        return fail("rt_tile_costs_export: this frame has not been rendered on the current lane since the scene was uploaded");
+    HIP_TRY(hipStreamSynchronize(lane.stream));
+    HIP_TRY(hipMemcpy(costs, lane.d_region_cost, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return use(0);
+}
+
+int rt_tile_costs_import(const rt_frame* frame, int gpu, const uint32_t* costs, uint32_t count) {
+    RegionKey key; uint32_t n = 0;
+    if (tile_cost_target(frame, gpu, &key, &n)) return 1;
+    if (count != n) return fail("rt_tile_costs_import: count differs from rt_tile_costs_count");
+    if (n == 0) return 0;
+    if (!costs) return fail("rt_tile_costs_import: costs is NULL");
+    if (use(gpu)) return 1;
+    Lane& lane = cur(gpu);
+    HIP_TRY(hipStreamSynchronize(lane.stream));
+    if (reserve_regions(lane, n)) return 1;
+    HIP_TRY(hipMemcpy(lane.d_region_cost, costs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(rtk_launch_sort_regions(lane.d_region_cost, n, lane.d_region_order, lane.stream));
+    lane.region_key = key; lane.region_key_valid = true;
+    return use(0);
 }
 
 int rt_select_lane(int lane) {

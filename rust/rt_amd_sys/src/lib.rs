@@ -103,6 +103,10 @@ extern "C" {
     pub fn rt_pack_rgb(d_pixels: *const u32, width: u32, height: u32, d_rgb: *mut u8) -> c_int;
     pub fn rt_assemble_tiles(d_gathered: *const u32, rows_per_shard_stride: u32, nshards: u32, tile_rows: u32, width: u32, height: u32,
                              d_frame: *mut u32) -> c_int;
+    /// Measured costs of the tile regions of a frame: out after a frame, back in before the first frame of a later run.
+    pub fn rt_tile_costs_count(frame: *const rt_frame, gpu: c_int, count: *mut u32) -> c_int;
+    pub fn rt_tile_costs_export(frame: *const rt_frame, gpu: c_int, costs: *mut u32, count: u32) -> c_int;
+    pub fn rt_tile_costs_import(frame: *const rt_frame, gpu: c_int, costs: *const u32, count: u32) -> c_int;
     /// `RT_LANES` = 4 lanes (stream + work buffers each); launches on different lanes may overlap on the GPU.
     pub fn rt_select_lane(lane: c_int) -> c_int;
     pub fn rt_stream() -> *mut c_void;

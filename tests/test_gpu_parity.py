@@ -247,6 +247,58 @@ def test_two_tracers_each_render_their_own_scene():
         assert diff == 0, path
 
 
+def test_tile_costs_carry_over_to_a_new_upload_and_change_no_pixel(tmp_path):
+    """The measured costs of the tile regions can be taken out after a frame and handed back after the scene has been
+    uploaded again (a later run of the same scene file): they set the order of the work of the first launch, nothing
+    else.  Arbitrary costs must give the same frame too."""
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
+    cfg.set_size(1280, 720)                                   # 160 x 90 tiles: regions of 8 x 8 tiles, 20 x 12 of them
+    scene, frame = cfg.scene(), cfg.frame()
+    rt.upload_scene(scene)
+    assert rt.tile_costs_count(frame) == 240
+    with pytest.raises(rt.RtError, match="has not been rendered"):
+        rt.tile_costs_export(frame)
+    first, _ = rt.render(frame)
+    first = first.copy()
+    costs = rt.tile_costs_export(frame)
+    assert costs.shape == (240,) and costs.max() > 0 and (costs > 0).sum() > 120
+    rt.upload_scene(scene)
+    with pytest.raises(rt.RtError, match="has not been rendered"):
+        rt.tile_costs_export(frame)
+    rt.tile_costs_import(frame, costs)
+    assert np.array_equal(rt.render(frame)[0], first)
+    rt.upload_scene(scene)
+    rt.tile_costs_import(frame, np.random.default_rng(3).integers(0, 2 ** 32, 240, dtype=np.uint64).astype(np.uint32))
+    assert np.array_equal(rt.render(frame)[0], first)
+    with pytest.raises(rt.RtError, match="count differs"):
+        rt.tile_costs_import(frame, costs[:-1])
+    with pytest.raises(rt.RtError, match="no such GPU"):
+        rt.tile_costs_count(frame, gpu=1)
+    cfg.set_size(64, 48)                                      # too few tiles to be ordered: nothing to save, nothing to do
+    small = cfg.frame()
+    assert rt.tile_costs_count(small) == 0
+    rt.tile_costs_import(small, np.zeros(0, np.uint32))
+    assert rt.tile_costs_export(small).shape == (0,)
+
+    # through the scene cache: the first start leaves the costs beside the cache, the second one picks them up
+    cfg.set_size(1280, 720)
+    src = tmp_path / "dragon.scene"
+    text = open(os.path.join(GOLDEN, "final_avec_bonus.scene")).read().replace("size 640 480", "size 1280 720")
+    assert "size 1280 720" in text
+    src.write_text(text)
+    one = rt.RayTracer.from_scene_file(str(src))
+    a = one.render().data.copy()
+    tiles = str(src) + ".rtcache.tiles"
+    assert not one.from_cache and os.path.getsize(tiles) > 240 * 4
+    two = rt.RayTracer.from_scene_file(str(src))
+    assert two.from_cache and rt.load_tile_costs(tiles, two.config.frame())
+    assert np.array_equal(two.render().data, a)
+    os.truncate(tiles, 100)                                   # a damaged file is ignored
+    three = rt.RayTracer.from_scene_file(str(src))
+    assert not rt.load_tile_costs(tiles, three.config.frame())
+    assert np.array_equal(three.render().data, a)
+
+
 def test_render_is_deterministic_and_instrumentation_does_not_change_pixels():
     cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
     tracer = rt.RayTracer.new(cfg)
