@@ -316,8 +316,8 @@ def main():
         launches = world if mode == "library" else 1                    # the counts above are spread over this many concurrent launches
         achieved = alg_bytes / launches / (k_ms * 1e-3) / 1e9
         pmc = load_counters(args.config)
-        # Neither workload is carried by HBM: measured HBM traffic per launch (traffic) is 0.3 % of the algorithmic bytes on the
-        # dragon (7 MB scene, L2 hit rate 98 %) and 5 % on the mesh (641 MB scene, L2 hit rate 85 %, the rest mostly from the
+        # Neither workload is carried by HBM: measured HBM traffic per launch (traffic) is 1.5 % of the algorithmic bytes on the
+        # dragon (7 MB scene, L2 hit rate 94 %) and 4 % on the mesh (641 MB scene, L2 hit rate 87 %, the rest mostly from the
         # 256 MB memory-side cache), so the memory-side bound of the traversal is the aggregate L2 bandwidth for both.
         bound, peak = "l2", L2_PEAK_GBS
         note = ("algorithmic bytes = 32 B x boxes tested + 48 B x shapes tested + 4 B x pixels, served by the caches (see traffic for what "
