@@ -118,6 +118,8 @@ class ShardedRenderer:
                 frame = [torch.zeros((height, width), dtype=torch.int32, device=self.device) for _ in range(L)]
                 if self._collectives:
                     gathered = [torch.zeros((self.world, stride, width), dtype=torch.int32, device=self.device) for _ in range(L)]
+            if torch.device(self.device).type == "cuda":
+                torch.cuda.synchronize(self.device)       # the fills run on torch's stream; the library's streams do not wait for it
             self._bufs[key] = (stride, local, gathered, frame)
         return self._bufs[key]
 
