@@ -15,6 +15,9 @@
  *     rt_last_error() describes it (the Err(String) of the reference); nothing aborts;
  *   - calls come from one thread at a time and are blocking, like the reference's render(), except where a
  *     function says it only enqueues work on rt_stream() (rt_render_tiles without stats, rt_assemble_tiles, rt_pack_rgb);
+ *   - the library works on streams of its own (rt_stream() is the current one), which do not wait for the default stream
+ *     or for anybody else's: device buffers handed to a call must be complete (whatever filled them has finished, or is
+ *     ordered before rt_stream() by an event), and results of calls that only enqueue are there after rt_synchronize();
  *   - a process drives one GPU (rt_init(device)) or the first n GPUs of its node (rt_init_multi(n)): the scene is then
  *     replicated with one RCCL broadcast and every frame is cut into interleaved row tiles over the GPUs and gathered on
  *     the first, all inside rt_upload_scene / rt_render, so the caller's code is the same.  Jobs of one process per GPU
