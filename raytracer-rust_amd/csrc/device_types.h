@@ -75,8 +75,9 @@ inline RenderPlan rtk_render_plan(int stack_depth, uint32_t maxdepth) {
     return p;
 }
 
-// regions[order[i]] by decreasing cost into `order` (n <= MAX_SORTED_REGIONS), ties by index.
-extern "C" hipError_t rtk_launch_sort_regions(const uint32_t* d_cost, uint32_t n, uint32_t* d_order, hipStream_t stream);
+// regions[order[i]] by decreasing cost into `order` (n <= MAX_SORTED_REGIONS), ties by index; the costs are moved to d_last
+// and d_cost is left zeroed.
+extern "C" hipError_t rtk_launch_sort_regions(uint32_t* d_cost, uint32_t n, uint32_t* d_order, uint32_t* d_last, hipStream_t stream);
 
 extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, uint32_t* d_out, float4* d_fold,
                                         unsigned long long* d_counters, int stack_depth, RenderPlan plan, int count, hipStream_t stream);

@@ -506,10 +506,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
 // Regions by decreasing measured cost (bitonic sort of one workgroup in LDS; keys cost << 32 | ~index so that
 // equal costs keep index order).
 // `padded`: the power of two the n keys are padded to (with keys that sort last).
-__global__ __launch_bounds__(1024) void sort_regions_kernel(const uint32_t* __restrict__ cost, uint32_t n, uint32_t padded, uint32_t* __restrict__ order) {
+// The costs move on to `last` (what rt_tile_costs_export hands out) and `cost` is left at zero for the next launch to
+// measure into: no separate clearing launch per frame.
+__global__ __launch_bounds__(1024) void sort_regions_kernel(uint32_t* __restrict__ cost, uint32_t n, uint32_t padded, uint32_t* __restrict__ order,
+                                                            uint32_t* __restrict__ last) {
     __shared__ unsigned long long keys[MAX_SORTED_REGIONS];
-    for (uint32_t i = threadIdx.x; i < padded; i += blockDim.x)
-        keys[i] = i < n ? (((unsigned long long)cost[i] << 32) | (0xFFFFFFFFu - i)) : 0ull;
+    for (uint32_t i = threadIdx.x; i < padded; i += blockDim.x) {
+        const uint32_t c = i < n ? cost[i] : 0u;
+        keys[i] = i < n ? (((unsigned long long)c << 32) | (0xFFFFFFFFu - i)) : 0ull;
+        if (i < n) { last[i] = c; cost[i] = 0u; }
+    }
     __syncthreads();
     for (uint32_t k = 2; k <= padded; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -565,11 +571,11 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     return hipGetLastError();
 }
 
-extern "C" hipError_t rtk_launch_sort_regions(const uint32_t* d_cost, uint32_t n, uint32_t* d_order, hipStream_t stream) {
+extern "C" hipError_t rtk_launch_sort_regions(uint32_t* d_cost, uint32_t n, uint32_t* d_order, uint32_t* d_last, hipStream_t stream) {
     if (n == 0 || n > MAX_SORTED_REGIONS) return hipErrorInvalidValue;
     uint32_t padded = 2;
     while (padded < n) padded <<= 1;
-    hipLaunchKernelGGL(sort_regions_kernel, dim3(1), dim3(padded < 1024 ? (padded < 64 ? 64 : padded) : 1024), 0, stream, d_cost, n, padded, d_order);
+    hipLaunchKernelGGL(sort_regions_kernel, dim3(1), dim3(padded < 1024 ? (padded < 64 ? 64 : padded) : 1024), 0, stream, d_cost, n, padded, d_order, d_last);
     return hipGetLastError();
 }
 

@@ -42,7 +42,7 @@ struct Lane {
     float4* d_fold = nullptr; size_t fold_cap = 0;          // records
     unsigned long long* d_counters = nullptr;               // nodes, prims, shadow, secondary, wave-level passes
     // order in which the tile regions of a launch are handed out, and what it was computed for
-    uint32_t* d_region_order = nullptr; uint32_t* d_region_cost = nullptr; uint32_t region_cap = 0;
+    uint32_t* d_region_order = nullptr; uint32_t* d_region_cost = nullptr; uint32_t* d_region_last = nullptr; uint32_t region_cap = 0;   // cost: being measured; last: of the launch before
     RegionKey region_key{}; bool region_key_valid = false;
     // frames over several GPUs: this GPU's compact rows; on the first GPU the gathered rows of all and the frame
     uint32_t* d_rows = nullptr; size_t rows_cap = 0;
@@ -215,9 +215,10 @@ RegionKey region_key(const rt_frame& fr, uint32_t shard, uint32_t nshards, uint3
 int reserve_regions(Lane& lane, uint32_t n_regions) {
     if (n_regions <= lane.region_cap) return 0;
     if (lane.d_region_order) { (void)hipFree(lane.d_region_order); lane.d_region_order = nullptr; lane.region_cap = 0; }
-    if (lane.d_region_cost) { (void)hipFree(lane.d_region_cost); lane.d_region_cost = nullptr; }
+    if (lane.d_region_cost) { (void)hipFree(lane.d_region_cost); lane.d_region_cost = nullptr; lane.d_region_last = nullptr; }
     HIP_TRY(hipMalloc((void**)&lane.d_region_order, (size_t)n_regions * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&lane.d_region_cost, (size_t)n_regions * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&lane.d_region_cost, 2 * (size_t)n_regions * sizeof(uint32_t)));
+    lane.d_region_last = lane.d_region_cost + n_regions;
     lane.region_cap = n_regions;
     return 0;
 }
@@ -234,10 +235,9 @@ int plan_regions(Lane& lane, const rt_frame& fr, DevFrame* f) {
         if (reserve_regions(lane, f->n_regions)) return 1;
         // All costs equal: the sort leaves the regions in index order.
         HIP_TRY(hipMemsetAsync(lane.d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), lane.stream));
-        HIP_TRY(rtk_launch_sort_regions(lane.d_region_cost, f->n_regions, lane.d_region_order, lane.stream));
+        HIP_TRY(rtk_launch_sort_regions(lane.d_region_cost, f->n_regions, lane.d_region_order, lane.d_region_last, lane.stream));
         lane.region_key = key; lane.region_key_valid = true;
     }
-    HIP_TRY(hipMemsetAsync(lane.d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), lane.stream));
     f->region_order = lane.d_region_order;
     f->region_cost = lane.d_region_cost;
     return 0;
@@ -288,7 +288,7 @@ int enqueue_shard(int d, const rt_frame* frame, uint32_t shard, uint32_t nshards
     if (plan_regions(lane, *frame, &f)) return 1;
     if (timed) HIP_TRY(hipEventRecord(lane.ev0, lane.stream));
     HIP_TRY(rtk_launch_render(&g.devs[d].dsc, &f, d_out, lane.d_fold, lane.d_counters, (int)g.hdr.max_depth, plan, count_work, lane.stream));
-    if (f.region_cost) HIP_TRY(rtk_launch_sort_regions(f.region_cost, f.n_regions, lane.d_region_order, lane.stream));
+    if (f.region_cost) HIP_TRY(rtk_launch_sort_regions(f.region_cost, f.n_regions, lane.d_region_order, lane.d_region_last, lane.stream));
     if (timed) HIP_TRY(hipEventRecord(lane.ev1, lane.stream));
     return 0;
 }
@@ -656,7 +656,7 @@ int rt_tile_costs_export(const rt_frame* frame, int gpu, uint32_t* costs, uint32
     if (!lane.region_key_valid || std::memcmp(&key, &lane.region_key, sizeof(key)) != 0)
         return fail("rt_tile_costs_export: this frame has not been rendered on the current lane since the scene was uploaded");
     HIP_TRY(hipStreamSynchronize(lane.stream));
-    HIP_TRY(hipMemcpy(costs, lane.d_region_cost, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(costs, lane.d_region_last, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return use(0);
 }
 
@@ -671,7 +671,7 @@ int rt_tile_costs_import(const rt_frame* frame, int gpu, const uint32_t* costs, 
     HIP_TRY(hipStreamSynchronize(lane.stream));
     if (reserve_regions(lane, n)) return 1;
     HIP_TRY(hipMemcpy(lane.d_region_cost, costs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(rtk_launch_sort_regions(lane.d_region_cost, n, lane.d_region_order, lane.stream));
+    HIP_TRY(rtk_launch_sort_regions(lane.d_region_cost, n, lane.d_region_order, lane.d_region_last, lane.stream));
     lane.region_key = key; lane.region_key_valid = true;
     return use(0);
 }
