@@ -37,7 +37,8 @@ struct DevFrame {
 };
 
 
-constexpr uint32_t MAX_SORTED_REGIONS = 4096;   // what one workgroup sorts in LDS
+constexpr uint32_t MAX_SORTED_REGIONS = 4096;
+#define RT_N_COUNTERS 12                         // 64-bit work counters of an instrumented launch (render_kernels.hip, rt_api.cpp)   // what one workgroup sorts in LDS
 
 // Region size for a launch of tiles_x x tiles_y pixel tiles: 0 = row-major tile order.
 // Frames of fewer than 2048 tiles keep row-major order; otherwise the smallest regions (from 8x8 tiles up) that
@@ -55,7 +56,8 @@ inline uint32_t region_log2_for(uint64_t tiles) {
 // 3.24 against 3.40 ms at four, 8K mesh 37 against 41 ms), a sixth (80 registers) spills inside the loops and loses.
 // LDS of one wavefront: a traversal stack of one entry per tree level plus two sentinels (256 bytes per entry), and behind
 // it the records of the first reflection levels (1 KiB per level), as many as fit; the records of deeper levels, which
-// fewer pixels reach, go to a global array.
+// fewer pixels reach, go to a global array.  Last come the 512 bytes of tables of the specular power (specular_pow.h).
+#define RT_POW_LDS_BYTES 512u
 #ifndef RT_WAVES
 #define RT_WAVES 5
 #endif
@@ -66,7 +68,7 @@ struct RenderPlan { uint32_t lds_levels; };          // reflection levels 0 .. l
 inline uint32_t rtk_stack_entries(int stack_depth) { return (uint32_t)(stack_depth < 6 ? 8 : stack_depth + 2); }     // two sentinels
 inline RenderPlan rtk_render_plan(int stack_depth, uint32_t maxdepth) {
     RenderPlan p;
-    const uint32_t levels = maxdepth > 1 ? maxdepth - 1u : 0u, stack_bytes = rtk_stack_entries(stack_depth) * 256u;
+    const uint32_t levels = maxdepth > 1 ? maxdepth - 1u : 0u, stack_bytes = rtk_stack_entries(stack_depth) * 256u + RT_POW_LDS_BYTES;
     const uint32_t room = stack_bytes < RT_LDS_PER_WAVE ? (RT_LDS_PER_WAVE - stack_bytes) / 1024u : 0u;
     p.lds_levels = levels < room ? levels : room;
 #ifdef RT_FOLD_GLOBAL

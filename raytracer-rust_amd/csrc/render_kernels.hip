@@ -24,6 +24,7 @@
 //   shading                       src/raytracer/raytracer.rs:160-181
 //   reflection                    src/raytracer/raytracer.rs:183-196
 //   sphere / plane / triangle     src/raytracer/config/shape.rs:72-96, 112-132, 149-191
+// The one library call of the path, powf (raytracer.rs:173), is the C library's algorithm in binary64 (specular_pow.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #ifdef RT_DIAG_LDS_PAD
@@ -33,6 +34,7 @@
 
 #include "device_types.h"
 #include "layout.h"
+#include "specular_pow.h"
 
 #pragma clang fp contract(off)
 
@@ -76,7 +78,22 @@ __device__ __forceinline__ float4 uniform_load(const float4* base, uint32_t inde
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-struct Counters { uint32_t nodes, prims, shadow, secondary, wave_node_iters, wave_prim_iters; };
+struct Counters {
+    uint32_t nodes, prims, shadow, secondary, wave_node_iters, wave_prim_iters;
+    uint32_t wave_closest, wave_hit, wave_shadow, wave_shade;      // wavefront-level passes through the phases of a path level
+    uint32_t wave_shadow_node_iters, wave_shadow_prim_iters;       // the share of shadow rays in wave_node_iters / wave_prim_iters
+};
+
+// Diagnostic builds (-DRT_MARKS, compiled to assembly only) leave comments in the instruction stream, from which
+// scripts/phase_table.py counts the instructions of each phase.
+#ifdef RT_MARKS
+#define MARK(name) asm volatile("; MARK " name)
+#define MARK_AT(name, site) asm volatile("; MARK " name "_%c0" : : "i"(site))      // a mark inside a function that is inlined at several sites
+#else
+#define MARK(name)
+#define MARK_AT(name, site)
+#endif
+enum Site { SITE_CLOSEST_LIST, SITE_CLOSEST_TREE, SITE_SHADOW_LIST, SITE_SHADOW_TREE };
 
 // True on exactly one of the currently active lanes.
 __device__ __forceinline__ bool first_active_lane() { return (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1); }
@@ -123,10 +140,12 @@ __device__ __forceinline__ bool test_plane(V3 p, V3 n, V3 o, V3 d, float* t_out)
     return true;
 }
 
+template <int SITE>
 __device__ __forceinline__ bool test_shape(const float4 q0, const float4 q1, const float4 q2, V3 o, V3 d, float* t_out) {
     uint32_t kind = __float_as_uint(q0.w) & 3u;
-    if (kind == KIND_TRIANGLE) return test_triangle(v3(q0), v3(q1), v3(q2), o, d, t_out);
-    if (kind == KIND_SPHERE) return test_sphere(v3(q0), q1.x, o, d, t_out);
+    if (kind == KIND_TRIANGLE) { MARK_AT("triangle", SITE); return test_triangle(v3(q0), v3(q1), v3(q2), o, d, t_out); }
+    if (kind == KIND_SPHERE) { MARK_AT("sphere", SITE); return test_sphere(v3(q0), q1.x, o, d, t_out); }
+    MARK_AT("plane", SITE);
     return test_plane(v3(q0), v3(q2), o, d, t_out);
 }
 
@@ -226,14 +245,18 @@ __device__ __forceinline__ void consider(Best* b, float t, uint32_t prim, uint32
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint32_t* stack, Best* best, Counters* cnt) {
     best->t = INF; best->prim = NO_PRIM; best->order = 0xFFFFFFFFu;
+    MARK("closest_list");
     for (uint32_t i = 0; i < sc.n_list; i++) {
         const float4 q0 = uniform_load(sc.list, 3 * i), q1 = uniform_load(sc.list, 3 * i + 1), q2 = uniform_load(sc.list, 3 * i + 2);
         float t;
         if (COUNT) cnt->prims++;
-        if (test_shape(q0, q1, q2, o, d, &t)) consider(best, t, LIST_FLAG | i, __float_as_uint(q1.w));
+        const bool hit = test_shape<SITE_CLOSEST_LIST>(q0, q1, q2, o, d, &t);
+        MARK_AT("tested", SITE_CLOSEST_LIST);
+        if (hit) consider(best, t, LIST_FLAG | i, __float_as_uint(q1.w));
     }
     uint32_t cur = sc.root_ref;
     if (cur == REF_EMPTY) return;
+    MARK("closest_raybox");
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = best->prim == NO_PRIM ? INF : prune_limit(best->t);
     // Entries 0 and 1 of every lane's stack hold REF_EMPTY: popping needs no emptiness test, and the two entries below
@@ -247,6 +270,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
     // pop right after a pop, then cost no LDS round trip of their own), the rest are selects.
     uint32_t held = 0;                                  // leaf set aside (leaf references are never 0)
     for (;;) {
+        MARK("closest_box");
         while (!(cur & REF_LEAF)) {
             const uint4* n = (const uint4*)((const char*)sc.nodes + cur);   // an inner reference is the pair's byte offset; 32 bits keep the address in one register
             const uint4 c0 = n[0], c1 = n[1];
@@ -271,6 +295,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             // nobody is still looking for a first leaf: no lane with empty hands and an inner node before it (one compare per lane)
             if (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) == 0) break;
         }
+        MARK("closest_shape");
         if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf
             held = cur;
             low -= 64; cur = low[128];
@@ -284,7 +309,9 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2];
                 float t;
                 if (COUNT) { cnt->prims++; if (first_active_lane()) cnt->wave_prim_iters++; }
-                if (test_shape(q0, q1, q2, o, d, &t)) {
+                const bool hit = test_shape<SITE_CLOSEST_TREE>(q0, q1, q2, o, d, &t);
+                MARK_AT("tested", SITE_CLOSEST_TREE);
+                if (hit) {
                     consider(best, t, first + k, __float_as_uint(q1.w));
                     tlim = prune_limit(best->t);
                 }
@@ -300,12 +327,19 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
 }
 
 // raytracer.rs:143-159 for one candidate.
+template <int SITE>
 __device__ __forceinline__ bool occludes(const float4 q0, const float4 q1, const float4 q2, V3 o, V3 d, bool hit_back, bool point_light,
                                          float light_dist) {
     float t;
-    if (!test_shape(q0, q1, q2, o, d, &t)) return false;
+    const bool hit = test_shape<SITE>(q0, q1, q2, o, d, &t);
+    MARK_AT("tested", SITE);
+    if (!hit) return false;
     if (t < 1e-6f) return false;
-    if (hit_back && shape_back_face(q0, q1, q2, d)) return false;
+    if (hit_back) {
+        MARK_AT("occluder_back_face", SITE);
+        if (shape_back_face(q0, q1, q2, d)) return false;
+    }
+    MARK_AT("guards", SITE);
     if (point_light) return t < light_dist;
     return true;
 }
@@ -313,16 +347,19 @@ __device__ __forceinline__ bool occludes(const float4 q0, const float4 q1, const
 template <bool COUNT>
 __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool hit_back, bool point_light, float light_dist, uint32_t* stack,
                                           Counters* cnt) {
+    MARK("shadow_list");
     for (uint32_t i = 0; i < sc.n_list; i++) {
         if (COUNT) cnt->prims++;
-        if (occludes(uniform_load(sc.list, 3 * i), uniform_load(sc.list, 3 * i + 1), uniform_load(sc.list, 3 * i + 2), o, d, hit_back, point_light, light_dist)) return true;
+        if (occludes<SITE_SHADOW_LIST>(uniform_load(sc.list, 3 * i), uniform_load(sc.list, 3 * i + 1), uniform_load(sc.list, 3 * i + 2), o, d, hit_back, point_light, light_dist)) return true;
     }
     uint32_t cur = sc.root_ref;
     if (cur == REF_EMPTY) return false;
+    MARK("shadow_raybox");
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = point_light ? prune_limit(light_dist) : INF;
     uint32_t* low = stack;                              // as in closest_hit: the next free entry is low[128]
     while (cur != REF_EMPTY) {
+        MARK("shadow_box");
         while (!(cur & REF_LEAF)) {
             const uint4* n = (const uint4*)((const char*)sc.nodes + cur);   // an inner reference is the pair's byte offset; 32 bits keep the address in one register
             const uint4 c0 = n[0], c1 = n[1];
@@ -331,21 +368,22 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
             float t0, t1;
             bool h0 = slab(c0, rb, tlim, &t0);
             bool h1 = slab(c1, rb, tlim, &t1);
-            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) cnt->wave_node_iters++; }
+            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) { cnt->wave_node_iters++; cnt->wave_shadow_node_iters++; } }
             const uint32_t r0 = c0.w, r1 = c1.w;
             const bool both = h0 && h1;
             if (both) low[128] = r1;
             cur = h0 ? r0 : (h1 ? r1 : below);
             low += both ? 64 : ((h0 || h1) ? 0 : -64);
         }
+        MARK("shadow_shape");
         if (cur != REF_EMPTY) {
             uint32_t first = (cur & ~REF_LEAF) >> 3, count = (cur & 7u) + 1u;
             uint32_t below = low[64];
             asm volatile("" : "+v"(below));       // read under the shape loads
             for (uint32_t k = 0; k < count; k++) {
                 const float4* p = sc.tree + 3 * (size_t)(first + k);
-                if (COUNT) { cnt->prims++; if (first_active_lane()) cnt->wave_prim_iters++; }
-                if (occludes(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
+                if (COUNT) { cnt->prims++; if (first_active_lane()) { cnt->wave_prim_iters++; cnt->wave_shadow_prim_iters++; } }
+                if (occludes<SITE_SHADOW_TREE>(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
             }
             low -= 64; cur = below;
         }
@@ -371,6 +409,19 @@ __device__ __forceinline__ uint32_t frame_row(const DevFrame& f, uint32_t r) {
 // Traversal stacks, [entry][lane]: sized at launch for the tree at hand (its depth plus the sentinel entry).
 extern __shared__ uint32_t s_stack[];
 
+// raytracer.rs:173.  On the C library's main path (a positive normal base: every n.h that is not exactly zero) its own
+// algorithm in binary64 with the tables in LDS; +0 to a positive power is +0; whatever else comes in goes to the device library.
+__device__ __forceinline__ float specular_power(float base, float exponent, const uint64_t* tables) {
+#ifdef RT_DIAG_NO_POWF        // (timing experiments only: what the power costs at all; wrong pixels)
+    return base;
+#endif
+#ifndef RT_LIBRARY_POWF      // (for comparisons: everything through the device library)
+    if (rtpow::pow_specular_domain(base, exponent)) return rtpow::pow_specular(base, exponent, tables);
+#endif
+    if (__float_as_uint(base) == 0u && exponent > 0.0f && exponent < INF) return 0.0f;
+    return powf(base, exponent);
+}
+
 // FOLD_LDS: the {local colour, material} records of the reflection levels live in LDS behind the stacks
 // ([level][lane], 16 bytes each), those of the deeper levels in the global `fold` array ([level - lds_levels][pixel]).
 template <bool COUNT>
@@ -379,6 +430,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
                                                                                                         uint32_t stack_entries, uint32_t lds_levels) {
     const uint32_t lane = threadIdx.x;
     float4* const fold_lds = (float4*)(s_stack + stack_entries * 64u) + lane;
+    uint64_t* const pow_tables = (uint64_t*)(s_stack + stack_entries * 64u + lds_levels * 256u);     // behind the records: RT_POW_LDS_BYTES
+    static_assert(rtpow::TABLE_WORDS == 64 && RT_POW_LDS_BYTES == 64 * sizeof(uint64_t), "one table word per lane");
+    pow_tables[lane] = rtpow::TABLES[lane];
     // Which 8x8 pixel tile this wavefront renders.  Workgroups are dealt round-robin over the 8
     // XCDs, each with an L2 of its own: in row-major order every XCD would touch every part of
     // the scene.  For big frames the blocks of one XCD instead sweep a square region of tiles at a
@@ -400,7 +454,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
     const uint32_t x = tile_x * 8u + (lane & 7u), r = tile_y * 8u + (lane >> 3);
     uint32_t* stack = s_stack + lane;
     stack[0] = REF_EMPTY; stack[64] = REF_EMPTY;
-    Counters cnt = {0u, 0u, 0u, 0u, 0u, 0u};
+    Counters cnt = {};
     const bool live = x < f.width && r < f.local_rows;
     if (live) {
         const uint32_t y = frame_row(f, r);
@@ -408,6 +462,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
         const size_t npix = (size_t)f.local_rows * f.width;
 
         // raytracer.rs:61-66
+        MARK("raygen");
         float b = (f.ph * (f.h2 - ((float)y + 0.5f))) / f.h2;
         float a = (f.pw * (((float)x + 0.5f) - f.w2)) / f.w2;
         V3 right = v3(f.right), up = v3(f.up), cv = v3(f.cv);
@@ -419,23 +474,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
         uint32_t depth = 0;
         for (;;) {
             Best best;
+            if (COUNT && first_active_lane()) cnt.wave_closest++;
             closest_hit<COUNT>(sc, o, d, stack, &best, &cnt);
+            MARK("hit");
             if (best.prim == NO_PRIM) { cur = v3(0.0f, 0.0f, 0.0f); break; }                    // raytracer.rs:199-201
 
             // Rebuild the reference's Intersection for the winner (shape.rs:84-95, 122-132, 178-191).
+            if (COUNT && first_active_lane()) cnt.wave_hit++;
             const float4* rec = (best.prim & LIST_FLAG) ? sc.list + 3 * (size_t)(best.prim & ~LIST_FLAG) : sc.tree + 3 * (size_t)best.prim;
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
             const uint32_t km = __float_as_uint(q0.w), kind = km & 3u, mat = km >> 2;
             V3 point = vadd(o, vscale(d, best.t));
             V3 normal; bool back = false;
             if (kind == KIND_TRIANGLE) {
+                MARK("hit_triangle");
                 normal = vnormalize(vcross(v3(q1), v3(q2)));      // the record holds the edges
                 back = vdot(normal, d) > 0.0f;
             } else if (kind == KIND_SPHERE) {
+                MARK("hit_sphere");
                 normal = vnormalize(vsub(point, v3(q0)));
             } else {
+                MARK("hit_plane");
                 normal = v3(q2);
             }
+            MARK("hit_material");
             const float4 m0 = sc.mats[2 * (size_t)mat], m1 = sc.mats[2 * (size_t)mat + 1];
             const V3 diffuse_color = v3(m0), specular_color = v3(m1);
             const float shininess = m0.w;
@@ -443,23 +505,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
             V3 acc = v3(0.0f, 0.0f, 0.0f);
             const V3 shadow_origin = vadd(point, vscale(normal, 1e-6f));                        // raytracer.rs:133
             for (uint32_t li = 0; li < sc.n_lights; li++) {                                      // raytracer.rs:126-179
+                MARK("light");
                 const float4 l0 = uniform_load(sc.lights, 2 * li), l1 = uniform_load(sc.lights, 2 * li + 1);
                 const bool point_light = l0.w == 0.0f;
                 V3 light_dir; float light_dist = 0.0f;
                 if (point_light) {
+                    MARK("light_point");
                     V3 to_light = vsub(v3(l0), point);
                     light_dir = vnormalize(to_light);
                     light_dist = vnorm(to_light);
                 } else {
+                    MARK("light_directional");
                     light_dir = v3(l0);
                 }
+                MARK("light_horizon");
                 if (COUNT) cnt.shadow++;
                 float n_dot_l = fmaxf(vdot(normal, light_dir), 0.0f);
                 // A light at or below the horizon of the surface adds (diffuse*0 + specular*0) (*) colour = +0
                 // whether or not it is occluded (unless shininess == 1, where the factor ignores n.l), so
                 // its shadow ray need not be traced.  Only valid while every factor is finite.
                 if (sc.finite_shading && n_dot_l == 0.0f && shininess != 1.0f) continue;
+                if (COUNT && first_active_lane()) cnt.wave_shadow++;
                 if (in_shadow<COUNT>(sc, shadow_origin, light_dir, back, point_light, light_dist, stack, &cnt)) continue;
+                MARK("shade");
+                if (COUNT && first_active_lane()) cnt.wave_shade++;
                 V3 diffuse = vscale(diffuse_color, n_dot_l);
                 V3 view_dir = vneg(d);
                 V3 half_vector = vnormalize(vadd(light_dir, view_dir));
@@ -467,10 +536,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
                 float factor;
                 if (shininess == 1.0f) factor = n_dot_h;
                 else if (shininess == 0.0f) factor = n_dot_l > 0.0f ? n_dot_h : 0.0f;
-                else factor = n_dot_l > 0.0f ? powf(n_dot_h, shininess) : 0.0f;
+                else { MARK("shade_pow"); factor = n_dot_l > 0.0f ? specular_power(n_dot_h, shininess, pow_tables) : 0.0f; }
+                MARK("shade_sum");
                 V3 specular = vscale(specular_color, factor);
                 acc = vadd(acc, vcmul(vadd(diffuse, specular), v3(l1)));
             }
+            MARK("level_end");
             V3 local = vadd(acc, ambient);                                                       // raytracer.rs:181
             bool reflective = specular_color.x > 0.0f || specular_color.y > 0.0f || specular_color.z > 0.0f;
             if (!(reflective && depth + 1u < f.maxdepth)) { cur = local; break; }                // raytracer.rs:187
@@ -484,18 +555,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
             if (COUNT) cnt.secondary++;
         }
         // Backward fold: final_k = local_k + specular_k (*) final_{k+1}                           raytracer.rs:194-195
+        MARK("fold");
         while (depth > 0) {
             depth--;
             const float4 rec = depth < lds_levels ? fold_lds[depth * 64u] : fold[(size_t)(depth - lds_levels) * npix + pix];
             const float4 m1 = sc.mats[2 * (size_t)__float_as_uint(rec.w) + 1];
             cur = vadd(v3(rec), vcmul(v3(m1), cur));
         }
+        MARK("quantise");
         out[pix] = quantise(cur);
     }
+    MARK("epilogue");
     if (f.region_cost && lane == 0) atomicMax(&f.region_cost[region], (uint32_t)(__builtin_amdgcn_s_memrealtime() - started));
     if (COUNT) {
-        unsigned long long v[6] = {cnt.nodes, cnt.prims, cnt.shadow, cnt.secondary, cnt.wave_node_iters, cnt.wave_prim_iters};
-        for (int k = 0; k < 6; k++) {
+        unsigned long long v[RT_N_COUNTERS] = {cnt.nodes, cnt.prims, cnt.shadow, cnt.secondary, cnt.wave_node_iters, cnt.wave_prim_iters,
+                                               cnt.wave_closest, cnt.wave_hit, cnt.wave_shadow, cnt.wave_shade, cnt.wave_shadow_node_iters,
+                                               cnt.wave_shadow_prim_iters};
+        for (int k = 0; k < RT_N_COUNTERS; k++) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&counters[k], s);
@@ -561,7 +637,7 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     size_t lds_bytes = (size_t)entries * 64 * sizeof(uint32_t);
     const uint32_t levels = f->maxdepth > 1 ? f->maxdepth - 1u : 0u;
     if (plan.lds_levels > levels) return hipErrorInvalidValue;
-    lds_bytes += (size_t)plan.lds_levels * 64 * sizeof(float4);
+    lds_bytes += (size_t)plan.lds_levels * 64 * sizeof(float4) + RT_POW_LDS_BYTES;
     if (lds_bytes > 64u * 1024u || (plan.lds_levels < levels && !d_fold)) return hipErrorInvalidValue;
 #ifdef RT_DIAG_LDS_PAD
     { static const char* pad = getenv("RT_DIAG_LDS_PAD"); if (pad) lds_bytes = std::max(lds_bytes, (size_t)atoi(pad)); }   // occupancy experiments (scripts/ab_occ.sh)

@@ -284,7 +284,7 @@ int enqueue_shard(int d, const rt_frame* frame, uint32_t shard, uint32_t nshards
     uint32_t levels = frame->maxdepth > 1 ? frame->maxdepth - 1 : 0;
     const RenderPlan plan = rtk_render_plan((int)g.hdr.max_depth, frame->maxdepth);
     if (plan.lds_levels < levels && ensure_fold(lane, npix, levels - plan.lds_levels)) return 1;
-    if (count_work) HIP_TRY(hipMemsetAsync(lane.d_counters, 0, 8 * sizeof(unsigned long long), lane.stream));
+    if (count_work) HIP_TRY(hipMemsetAsync(lane.d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), lane.stream));
     if (plan_regions(lane, *frame, &f)) return 1;
     if (timed) HIP_TRY(hipEventRecord(lane.ev0, lane.stream));
     HIP_TRY(rtk_launch_render(&g.devs[d].dsc, &f, d_out, lane.d_fold, lane.d_counters, (int)g.hdr.max_depth, plan, count_work, lane.stream));
@@ -304,10 +304,11 @@ int collect_stats(int d, const rt_frame* frame, uint32_t shard, uint32_t nshards
     const uint32_t local_rows = rt_shard_rows(frame->height, shard, nshards, tile_rows);
     stats->primary += (uint64_t)local_rows * frame->width;
     if (count_work && local_rows) {
-        unsigned long long c[8];
+        unsigned long long c[RT_N_COUNTERS];
         HIP_TRY(hipMemcpy(c, lane.d_counters, sizeof(c), hipMemcpyDeviceToHost));
         stats->nodes_visited += c[0]; stats->prims_tested += c[1]; stats->shadow += c[2]; stats->secondary += c[3];
         stats->box_passes += c[4]; stats->shape_passes += c[5];
+        for (int k = 0; k < 6; k++) stats->phase_passes[k] += c[6 + k];
     }
     return 0;
 }
@@ -388,7 +389,7 @@ int init_devices(int first_device, int count) {
             HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreate(&l.ev0));
             HIP_TRY(hipEventCreate(&l.ev1));
-            HIP_TRY(hipMalloc((void**)&l.d_counters, 8 * sizeof(unsigned long long)));
+            HIP_TRY(hipMalloc((void**)&l.d_counters, 16 * sizeof(unsigned long long)));
         }
         HIP_TRY(rtk_noalloc_setup(dev.device));
     }
