@@ -14,11 +14,17 @@ with one RCCL gather of the compact row buffers on GPU 0, which restores frame o
 drive them:
   --multi library (default)  rank 0 drives all N GPUs through the C ABI (rt_init_multi: RCCL inside the
                              library, what a single-process host like the reference's main gets); the
-                             other ranks only take part in the barriers.  If the library path cannot be
-                             set up, the line says so and the ranks path below is used instead.
+                             other ranks only take part in the barriers.  If the library path fails
+                             while it is set up (communicators, scene broadcast, a first gathered frame), the
+                             line says so and the ranks path below is used instead.
   --multi ranks              one process per GPU, torch.distributed ("nccl" = RCCL) for broadcast and gather.
 Frames are pipelined over the library's lanes (two deep up to four GPUs, four deep beyond): the gather of
 one frame overlaps the kernels of the next.  The total work is fixed as N grows: "scaling": "strong".
+
+With more than one GPU the frame that comes out of the gather is first compared, pixel for pixel, with the same
+frame rendered by GPU 0 alone (`multi_gpu_frame_equal`, both checksums in the line; a difference voids the line and
+the exit status is 4), and every step that can block inside a collective runs under a watchdog that ends the process
+with exit status 3 and a message naming the step.
 
 Rank 0 prints ONE JSON line.  `value` counts primary + shadow rays per second (the wording of
 the metric); reflection rays are traced too and reported in `mrays_all_per_s`.  Ray counts are
@@ -28,7 +34,9 @@ import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,7 +49,47 @@ import __graft_entry__ as ge  # noqa: E402
 SCENE = os.path.join(ROOT, "tests", "golden", "final_avec_bonus.scene")
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth of MI355X (the dragon's 7 MB scene is cache resident: L2 is the memory-side bound)
-SIMDS, CLOCK_HZ = 1024, 2.4e9
+SIMDS, XCDS = 1024, 8
+
+
+class Watchdog:
+    """Ends the process (exit status 3, a message on stderr saying which step hung) when a step that can block inside a
+    collective does not finish in time: a hung ncclGroupEnd must end the run with a diagnosis, not with silence."""
+
+    def __init__(self):
+        self._timer = None
+
+    def arm(self, seconds, what):
+        self.disarm()
+        self._timer = threading.Timer(seconds, self._fire, (seconds, what))
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+    @staticmethod
+    def _fire(seconds, what):
+        sys.stderr.write(f"bench.py: watchdog: {what} did not finish within {seconds:.0f} s; giving up (exit status 3)\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+
+def frame_checksum(frame_host):
+    return int(np.bitwise_xor.reduce(frame_host.reshape(-1).astype(np.uint64) * np.arange(1, frame_host.size + 1, dtype=np.uint64)))
+
+
+def counters_commit(entry):
+    """The commit the counter passes of profiles/traffic.json were taken at (the canned figures of the line come from that file)."""
+    if entry.get("profiled_at_commit"):
+        return entry["profiled_at_commit"]
+    try:
+        return subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "profiles/traffic.json"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or "unknown"
+    except (OSError, subprocess.SubprocessError):
+        return "unknown"
 
 
 def cpu_baseline_dragon(oracle, width, height):
@@ -138,32 +186,17 @@ def main():
         dist.broadcast(flag, src=0)
         return bool(flag.item())
 
-    # ------------------------------------------------------------------ how the GPUs are driven
-    mode, library_error = ("single" if world == 1 and not rehearse else args.multi), None
-    if mode == "library":
-        ok = True
-        if rank == 0:
-            try:
-                rt.init_multi(world)
-            except Exception as e:      # noqa: BLE001  (reported in the line; the ranks path takes over)
-                ok, library_error = False, str(e)
-                rt.shutdown()
-        if not agree(ok):
-            mode = "ranks"
-    elif mode == "single":
-        rt.init(0)
-
     # ------------------------------------------------------------------ the workload
     cfg = scene = None
     W, H = (args.width or (3840 if args.config == "dragon" else 7680)), (args.height or (2160 if args.config == "dragon" else 4320))
-    drives_gpus = mode == "ranks" or rank == 0
+    mode, library_error = ("single" if world == 1 and not rehearse else args.multi), None
+    gpu_build = args.config == "mesh"
     frame = None
     if args.config == "dragon":
-        if drives_gpus:
-            cfg = rt.ParsedConfigState().load_config_file(SCENE)
-            cfg.set_size(W, H)
-            frame = cfg.frame()
-            scene = cfg.scene() if rank == 0 else None
+        cfg = rt.ParsedConfigState().load_config_file(SCENE)
+        cfg.set_size(W, H)
+        frame = cfg.frame()
+        scene = cfg.scene() if rank == 0 else None
         workload = f"final_avec_bonus.scene (dragon, 100000 triangles + plane, 2 point lights, maxdepth 5) at {W}x{H}"
         data = ("reference scene file final_avec_bonus.scene with the size line overridden to 3840 2160" if (W, H) == (3840, 2160)
                 else f"reference scene file final_avec_bonus.scene at {W}x{H}")
@@ -174,20 +207,48 @@ def main():
         frame = syn.product_frame(rt, W, H)
         workload = f"procedural height-field mesh, 9998592 triangles + plane, 4 point lights, maxdepth 3, at {W}x{H}"
         data = "synthetic mesh generated in memory (raytracer-rust_amd/synthetic.py)"
-    gpu_build = args.config == "mesh"
 
+    # ------------------------------------------------------------------ how the GPUs are driven
+    # Library path: rank 0 sets up everything that can fail or hang inside RCCL (communicators, the broadcast of the scene,
+    # one whole frame through the gather) under a watchdog before anything is timed.  An error there is reported in the line
+    # and the ranks path takes over in the same processes; a hang ends the run with a message that names the step.
+    watchdog = Watchdog()
     t_up = time.perf_counter()
+    bvh_info = None
+    if mode == "library":
+        ok = True
+        if rank == 0:
+            try:
+                watchdog.arm(180, f"rt_init_multi({world}) (ncclCommInitAll over {world} GPUs)")
+                rt.init_multi(world)
+                watchdog.arm(600, "rt_upload_scene on the library path (tree build, upload and ncclBroadcast of the scene)")
+                bvh_info = rt.upload_scene(scene, gpu_build=gpu_build)
+                watchdog.arm(180, "the first frame on the library path (tile kernels, grouped ncclSend/ncclRecv gather, reassembly)")
+                rt.render_frame(frame, want_stats=True)
+            except Exception as e:      # noqa: BLE001  (reported in the line; the ranks path takes over)
+                ok, library_error = False, f"{type(e).__name__}: {e}"
+                watchdog.arm(120, "rt_shutdown after a failure on the library path")
+                rt.shutdown()
+            watchdog.disarm()
+        if not agree(ok):
+            mode = "ranks"
+    elif mode == "single":
+        rt.init(0)
+        bvh_info = rt.upload_scene(scene, gpu_build=gpu_build)
+    drives_gpus = mode == "ranks" or rank == 0
+
     renderer = group = None
     if mode == "ranks":
         torch.cuda.set_device(local_rank)
+        watchdog.arm(900, "setting up the ranks path (process group, scene broadcast)")
         if dist.is_initialized():
             group = dist.new_group(backend="nccl")
         renderer, bvh_info = shard_mod.gpu_renderer(rt, local_rank, scene=scene, always_gather=dist.is_initialized(), lanes=args.lanes or None,
                                                     gpu_build=gpu_build, group=group)
+        watchdog.disarm()
         lanes = renderer.lanes
         device = renderer.device
     else:
-        bvh_info = rt.upload_scene(scene, gpu_build=gpu_build) if rank == 0 else None
         lanes = args.lanes or (1 if world == 1 else shard_mod.default_lanes(world))
         device = torch.device("cuda", 0)
     upload_s = time.perf_counter() - t_up
@@ -220,6 +281,40 @@ def main():
         if dist.is_initialized():
             dist.barrier()
 
+    def to_host(ptr):
+        """A frame in device memory of the first GPU (raw pointer) copied to the host."""
+        import ctypes
+        host = np.empty((H, W), dtype=np.uint32)
+        hip = ctypes.CDLL(None)      # the HIP runtime already loaded into the process
+        assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(host.nbytes), 2) == 0      # device to host
+        return host
+
+    # ------------------------------------------------------------------ the frame of N GPUs must be the frame of one
+    # Before anything is timed: the same frame rendered by the first GPU alone (one shard of one) and through the path
+    # the timed loop uses; they must agree in every pixel, and the line carries both checksums.
+    one_gpu_checksum = multi_equal = None
+    if world > 1 or rehearse:
+        watchdog.arm(600, f"the check frame on the {mode} path (N GPUs against one GPU)")
+        alone = None
+        if rank == 0:
+            rt.select_lane(0)
+            ref = torch.zeros((H, W), dtype=torch.int32, device=device)
+            rt.after_torch()
+            rt.render_tiles(frame, 0, 1, ref.data_ptr(), want_stats=True)
+            alone = ref.cpu().numpy().view(np.uint32)
+            one_gpu_checksum = frame_checksum(alone)
+            del ref
+        if mode == "ranks":
+            out = renderer.render_frame(frame)
+            renderer.flush()
+            if rank == 0:
+                torch.cuda.synchronize(device)
+                multi_equal = bool(np.array_equal(out.cpu().numpy().view(np.uint32), alone))
+        elif rank == 0:
+            ptr, _ = rt.render_frame(frame, want_stats=True)
+            multi_equal = bool(np.array_equal(to_host(ptr), alone))
+        watchdog.disarm()
+
     # ------------------------------------------------------------------ timed region
     ext = None
     if mode != "ranks" and rank == 0:
@@ -248,6 +343,7 @@ def main():
         if events: events[1].record(ext[lane])
         return ptr
 
+    watchdog.arm(1200, f"warm-up and timed frames on the {mode} path")
     for _ in range(args.warmup):
         one_frame()
     if mode == "ranks":
@@ -262,6 +358,7 @@ def main():
         renderer.flush()          # the last frame's gather and reassembly belong to the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
+    watchdog.disarm()
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -271,12 +368,10 @@ def main():
         if mode == "ranks":
             frame_host = out.cpu().numpy().view(np.uint32)
         else:
-            frame_host = np.empty((H, W), dtype=np.uint32)
-            t_view = torch.from_numpy(frame_host.view(np.int32))
-            import ctypes
-            hip = ctypes.CDLL(None)      # the HIP runtime already loaded into the process
-            assert hip.hipMemcpy(ctypes.c_void_p(t_view.data_ptr()), ctypes.c_void_p(out), ctypes.c_size_t(frame_host.nbytes), 2) == 0      # device to host
-        checksum = int(np.bitwise_xor.reduce(frame_host.reshape(-1).astype(np.uint64) * np.arange(1, frame_host.size + 1, dtype=np.uint64)))
+            frame_host = to_host(out)
+        checksum = frame_checksum(frame_host)
+        if multi_equal is not None:
+            multi_equal = multi_equal and checksum == one_gpu_checksum       # the last timed frame too
 
     # Kernel-only duration (events bracketing just the kernel; the loop above brackets kernel + gather + reassembly),
     # the first frame of a freshly uploaded scene (no tile order from a previous launch yet), and the frame delivered to
@@ -323,20 +418,31 @@ def main():
         # dragon (7 MB scene, L2 hit rate 94 %) and 4 % on the mesh (641 MB scene, L2 hit rate 87 %, the rest mostly from the
         # 256 MB memory-side cache), so the memory-side bound of the traversal is the aggregate L2 bandwidth for both.
         bound, peak = "l2", L2_PEAK_GBS
-        note = ("algorithmic bytes = 32 B x boxes tested + 48 B x shapes tested + 4 B x pixels, served by the caches (see traffic for what "
-                "reaches HBM), hence compared with the aggregate L2 bandwidth; what limits the kernel is vector ALU issue (valu_issue_frac of "
-                "the SIMDs' issue slots, at 4 wavefronts per SIMD, mesh: 5) spent at valu_lane_use of the lanes: a wavefront runs as long "
-                "as its slowest ray")
+        note = ("achieved and frac are measured in this run: algorithmic bytes (32 B x boxes tested + 48 B x shapes tested + 4 B x pixels, "
+                "counted by the instrumented kernel) over the kernel's duration by HIP events on its stream, against the aggregate L2 "
+                "bandwidth, because the caches serve these bytes (traffic is what reaches HBM).  A box is 16 B in the node layout, so the "
+                "kernel requests requested_bytes_per_launch; frac_of_requested_bytes is the same fraction with those.  The fields named in "
+                "counters_source come from committed rocprofv3 --pmc passes, not from this run.  What limits the kernel is vector ALU issue "
+                "(valu_issue_frac of the SIMDs' issue slots, 5 wavefronts per SIMD) spent at valu_lane_use of the lanes: a wavefront runs as "
+                "long as its slowest ray")
         roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                     "traffic": pmc.get("hbm_bytes_per_launch"),
                     "kernel": "render_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes / launches,
-                    "requested_bytes_per_launch": requested / launches, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "note": note}
+                    "requested_bytes_per_launch": requested / launches,
+                    "frac_of_requested_bytes": requested / launches / (k_ms * 1e-3) / 1e9 / peak,
+                    "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "note": note}
+        canned = []
         if pmc.get("hbm_bytes_per_launch"):
             roofline["hbm_traffic_frac_of_peak"] = pmc["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if pmc.get("valu_insts"):
-            roofline["valu_issue_frac"] = pmc["valu_insts"] * 4 / (SIMDS * CLOCK_HZ * k_ms * 1e-3)
+            canned += ["traffic", "hbm_traffic_frac_of_peak (canned bytes over this run's kernel time)"]
+        if pmc.get("valu_insts") and pmc.get("gui_active_cycles_all_xcds"):
+            # issue slots: one vector instruction per SIMD every 4 cycles, over the cycles the same profiled launch took
+            roofline["valu_issue_frac"] = pmc["valu_insts"] * 4 / (SIMDS * pmc["gui_active_cycles_all_xcds"] / XCDS)
             roofline["valu_lane_use"] = pmc.get("valu_lane_utilisation")
             roofline["l2_hit_rate"] = pmc.get("l2_hit_rate")
+            canned += ["valu_issue_frac", "valu_lane_use", "l2_hit_rate"]
+        roofline["counters_source"] = (f"profiles/traffic.json @ {counters_commit(pmc)} ({pmc.get('source', 'no entry for this workload')}): " + ", ".join(canned)
+                                       if canned else None)
         result = {
             "metric": "Mrays/sec (primary+shadow) at 3840x2160 dragon scene" if args.config == "dragon" else "Mrays/sec (primary+shadow), 10M-triangle mesh at 7680x4320",
             "value": rays_ps * args.steps / elapsed / 1e6,
@@ -366,6 +472,11 @@ def main():
             "frame_checksum": checksum,
             "roofline": roofline,
         }
+        if multi_equal is not None:
+            result["multi_gpu_frame_equal"] = multi_equal
+            result["frame_checksum_one_gpu"] = one_gpu_checksum
+            if not multi_equal:
+                result["error"] = "the frame gathered from the GPUs differs from the frame of one GPU: the numbers of this line are void"
         if library_error:
             result["config"]["library_path_error"] = library_error
         if world == 1 and not args.no_cpu_baseline:
@@ -376,6 +487,8 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and multi_equal is False:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -17,7 +17,8 @@
  *     function says it only enqueues work on rt_stream() (rt_render_tiles without stats, rt_assemble_tiles, rt_pack_rgb);
  *   - the library works on streams of its own (rt_stream() is the current one), which do not wait for the default stream
  *     or for anybody else's: device buffers handed to a call must be complete (whatever filled them has finished, or is
- *     ordered before rt_stream() by an event), and results of calls that only enqueue are there after rt_synchronize();
+ *     ordered before rt_stream() by an event: rt_wait_event), and results of calls that only enqueue are there after
+ *     rt_synchronize() or behind an event recorded with rt_record_event;
  *   - a process drives one GPU (rt_init(device)) or the first n GPUs of its node (rt_init_multi(n)): the scene is then
  *     replicated with one RCCL broadcast and every frame is cut into interleaved row tiles over the GPUs and gathered on
  *     the first, all inside rt_upload_scene / rt_render, so the caller's code is the same.  Jobs of one process per GPU
@@ -235,6 +236,15 @@ int rt_tile_costs_import(const rt_frame* frame, int gpu, const uint32_t* costs, 
  * device work or events against it (a frame over several GPUs ends on it), and a wait for the current lane of every GPU. */
 void* rt_stream(void);
 int rt_synchronize(void);
+
+/* Ordering against work on other streams without waiting on the host.  rt_wait_event: everything enqueued on the current
+ * lane after this call runs after `hip_event` (a hipEvent_t the caller has recorded on the stream that fills the buffers it
+ * is about to hand in: a memset or a kernel of its own on the default stream, say).  rt_record_event: records the caller's
+ * event behind everything enqueued on the current lane so far (a frame over several GPUs ends there), for the caller's
+ * stream to wait on before it reads a result.  Both refer to the first GPU's stream of the current lane and return at
+ * once.  No counterpart in the reference (it has one address space and no streams). */
+int rt_wait_event(void* hip_event);
+int rt_record_event(void* hip_event);
 
 /* Err(String) of the last failing call on this thread. */
 const char* rt_last_error(void);

@@ -100,6 +100,8 @@ _SIGNATURES = {
     "rt_select_lane": (C.c_int, [C.c_int]),
     "rt_stream": (C.c_void_p, []),
     "rt_synchronize": (C.c_int, []),
+    "rt_wait_event": (C.c_int, [C.c_void_p]),
+    "rt_record_event": (C.c_int, [C.c_void_p]),
     "rt_last_error": (C.c_char_p, []),
     "rt_shutdown": (None, []),
     "rth_load_config_file": (C.c_void_p, [C.c_char_p]),
@@ -377,18 +379,19 @@ def device_count():
 
 
 def shutdown():
-    global _bound_device
+    global _bound_device, _resident_token
     if _lib is not None:
         _lib.rt_shutdown()
     _bound_device = None
+    _resident_token += 1            # no scene is resident any more: every RayTracer uploads its own again after the next init
 
 
 BUILD_ON_GPU = 1
+_resident_token = 0
 
 # The library keeps ONE scene resident.  Every upload takes a new token; a RayTracer whose
 # token is no longer the current one makes its own scene resident again before it renders (the reference's RayTracer
 # owns its Config and Bvh, so holding several at once is valid there).
-_resident_token = 0
 
 
 def _new_resident_token():
@@ -399,8 +402,10 @@ def _new_resident_token():
 
 def upload_scene(scene, gpu_build=False):
     """RayTracer::new: tree build (split search on the host, or on the GPU with gpu_build=True) + upload."""
-    _check(lib().rt_upload_scene_ex(C.byref(scene), BUILD_ON_GPU if gpu_build else 0))
-    _new_resident_token()
+    try:
+        _check(lib().rt_upload_scene_ex(C.byref(scene), BUILD_ON_GPU if gpu_build else 0))
+    finally:
+        _new_resident_token()       # also when it failed: the scene that was resident may be gone
     info = rt_bvh_info()
     _check(lib().rt_get_bvh_info(C.byref(info)))
     return info.as_dict()
@@ -417,8 +422,10 @@ def copy_scene_blob(device_dst, nbytes):
 
 
 def adopt_scene_blob(device_ptr, nbytes):
-    _check(lib().rt_adopt_scene_blob(C.c_void_p(device_ptr), nbytes))
-    _new_resident_token()
+    try:
+        _check(lib().rt_adopt_scene_blob(C.c_void_p(device_ptr), nbytes))
+    finally:
+        _new_resident_token()
 
 
 def upload_scene_blob(blob):
@@ -428,8 +435,10 @@ def upload_scene_blob(blob):
     else:
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         ptr, n = blob.ctypes.data, blob.size
-    _check(lib().rt_upload_scene_blob(C.c_void_p(ptr), n))
-    _new_resident_token()
+    try:
+        _check(lib().rt_upload_scene_blob(C.c_void_p(ptr), n))
+    finally:
+        _new_resident_token()
     info = rt_bvh_info()
     _check(lib().rt_get_bvh_info(C.byref(info)))
     return info.as_dict()
@@ -553,6 +562,37 @@ def stream():
     return lib().rt_stream()
 
 
+def wait_event(hip_event):
+    """Work enqueued on the current lane from now on runs after `hip_event` (a hipEvent_t handle, e.g. torch.cuda.Event.cuda_event)."""
+    _check(lib().rt_wait_event(C.c_void_p(hip_event)))
+
+
+def record_event(hip_event):
+    """Records `hip_event` behind the work enqueued on the current lane so far."""
+    _check(lib().rt_record_event(C.c_void_p(hip_event)))
+
+
+def after_torch(torch_stream=None):
+    """Orders the current lane behind what has been enqueued on a torch stream (default: torch's current stream) so far:
+    tensors filled there may be handed to the library right away, without a host-side wait."""
+    import torch
+    ev = torch.cuda.Event()
+    ev.record(torch_stream if torch_stream is not None else torch.cuda.current_stream())
+    wait_event(ev.cuda_event)
+    return ev           # (keep it alive until the lane has passed it; rt_synchronize or any later wait does)
+
+
+def before_torch(torch_stream=None):
+    """The inverse: a torch stream (default: the current one) waits for what the current lane has been given so far."""
+    import torch
+    target = torch_stream if torch_stream is not None else torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(target)                   # torch creates the HIP event on its first record; the library then records it anew
+    record_event(ev.cuda_event)
+    target.wait_event(ev)
+    return ev
+
+
 def tile_costs_count(frame, gpu=0):
     """Number of tile regions whose cost a launch of `frame` on GPU `gpu` measures (0: too small a frame to be ordered)."""
     n = C.c_uint32(0)
@@ -617,8 +657,9 @@ class RayTracer:
     """RayTracer of raytracer.rs:16-83 on one MI355X."""
 
     def __init__(self, config, device=None, gpu_build=False):
+        self._device = 0 if device is None else device
         if _bound_device is None:
-            init(0 if device is None else device)
+            init(self._device)
         self.config = config
         self._scene = config.scene() if isinstance(config, Config) else config.c
         self._gpu_build, self._cache_path = gpu_build, None
@@ -644,6 +685,7 @@ class RayTracer:
             init(0 if device is None else device)
         cache_path = cache_path or (os.fspath(path) + ".rtcache")
         self = cls.__new__(cls)
+        self._device = 0 if device is None else device
         self.last_stats = None
         self._cache_path, self._gpu_build = cache_path, False
         self._tiles_path, self._tiles_token = cache_path + ".tiles", None
@@ -673,9 +715,12 @@ class RayTracer:
         return self
 
     def _make_resident(self):
-        """Uploads this tracer's scene again if another RayTracer has replaced it since."""
+        """Uploads this tracer's scene again if it is no longer the resident one: another RayTracer has replaced it, an
+        upload has failed in between, or the library has been shut down (then it is bound to a device again first)."""
         if self._token == _resident_token:
             return
+        if _bound_device is None:
+            init(self._device)
         if self._scene is not None:
             upload_scene(self._scene, gpu_build=self._gpu_build)
         else:

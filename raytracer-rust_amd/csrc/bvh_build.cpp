@@ -297,6 +297,8 @@ struct Builder {
 struct Reinserter {
     static constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t n_inner = 0, root = NONE, depth_limit = 0;
+    uint32_t undone = 0;                  // reinsertions taken back for want of a place within the depth limit
+    uint32_t refuse_every = 0, searches = 0;   // tests: every refuse_every-th search for a place is made to fail
     std::vector<Box> box;                 // inner nodes 0 .. n_inner-1, leaves from n_inner on
     std::vector<uint32_t> parent, left, right, leaf_ref, height;     // height: node pairs on the longest way down (0 for a leaf)
     std::vector<double> area;
@@ -366,23 +368,45 @@ struct Reinserter {
         if (left[p] == old_child) left[p] = new_child; else right[p] = new_child;
     }
 
-    // Takes inner node v out, reinserts its two children.  Returns false (tree untouched) when v sits too close to the root.
+    // The free node f becomes the parent of x and t, in x's place.
+    void attach(uint32_t f, uint32_t x, uint32_t t) {
+        const uint32_t xp = parent[x];
+        left[f] = x; right[f] = t; parent[f] = xp; parent[x] = f; parent[t] = f;
+        if (xp == NONE) root = f; else replace_child(xp, x, f);
+        refit(f);
+    }
+
+    // Undoes attach(f, x, t): x takes f's place again, f and t are loose.
+    void detach(uint32_t f) {
+        const uint32_t x = left[f], fp = parent[f];
+        parent[x] = fp;
+        if (fp == NONE) root = x; else { replace_child(fp, f, x); refit(fp); }
+    }
+
+    // Takes inner node v out, reinserts its two children.  Returns false, with the tree as it was, when v sits too close to
+    // the root or when one of the children finds no place that keeps the tree within the depth limit (the first always
+    // does, its old place; the second need not once the first sits somewhere else).
     bool reinsert_children_of(uint32_t v) {
         const uint32_t p = parent[v];
         if (v == root || p == NONE || p == root) return false;
         const uint32_t g = parent[p], s = left[p] == v ? right[p] : left[p];
-        uint32_t loose[2] = {left[v], right[v]}, spare[2] = {v, p};
+        const uint32_t child[2] = {left[v], right[v]};
+        uint32_t loose[2] = {child[0], child[1]}, spare[2] = {v, p};
         if (area[loose[0]] < area[loose[1]]) std::swap(loose[0], loose[1]);          // the larger one first
         replace_child(g, p, s); parent[s] = g;
         refit(g);
         for (int k = 0; k < 2; k++) {
-            const uint32_t t = loose[k], f = spare[k];
-            uint32_t x = best_position(t);
-            if (x == NONE) x = s;                                                    // (cannot happen: the old place always fits)
-            const uint32_t xp = parent[x];
-            left[f] = x; right[f] = t; parent[f] = xp; parent[x] = f; parent[t] = f;
-            if (xp == NONE) root = f; else replace_child(xp, x, f);
-            refit(f);
+            uint32_t x = best_position(loose[k]);
+            if (refuse_every != 0 && ++searches % refuse_every == 0) x = NONE;       // (tests: the rare case on demand)
+            if (x == NONE) {                                                         // put everything back
+                undone++;
+                if (k == 1) detach(spare[0]);
+                left[v] = child[0]; right[v] = child[1]; parent[child[0]] = v; parent[child[1]] = v; parent[v] = NONE;
+                refit(v);
+                attach(p, s, v);
+                return false;
+            }
+            attach(spare[k], x, loose[k]);
         }
         return true;
     }
@@ -527,11 +551,13 @@ bool build_bvh(const float* lo, const float* hi, uint32_t n, uint32_t depth_limi
     if (sweeps > 0 && !(root_ref & rtl::REF_LEAF) && out->pairs.size() >= 8 && n <= REINSERT_MAX_SHAPES) {
         Reinserter r;
         r.depth_limit = out->max_depth;               // no deeper than the build made it: the traversal stacks are sized by it
+        if (const char* refuse = getenv("RT_BVH_TEST_REFUSE_EVERY")) r.refuse_every = (uint32_t)atoi(refuse);
         r.load(out->pairs, root_ref);
         r.store(out);                                 // numbered from the root down, whatever order the build's threads took their pairs in
         r.load(out->pairs, out->root_ref);
         r.run((uint32_t)sweeps);
         r.store(out);
+        if (getenv("RT_BVH_TRACE")) fprintf(stderr, "reinsertion: %u shapes, depth limit %u, %u reinsertions taken back\n", n, r.depth_limit, r.undone);
     }
     return true;
 }

@@ -539,8 +539,10 @@ struct CacheHeader {
     float cam_pos[3], cam_look[3], cam_up[3], cam_fov, ambient[3];
     uint32_t ntri, nsph, npl, nlights;
     char output_file[1024];
+    uint32_t reserved;             // zero (spelt out so that the struct has no padding: every byte of it is written and hashed)
     uint64_t header_hash;          // of the whole header block with this field zero: damage to the Config fields is noticed too
 };
+static_assert(offsetof(CacheHeader, header_hash) == 1160 && sizeof(CacheHeader) == 1168, "cache header layout (no padding)");
 constexpr size_t CACHE_HEADER_BYTES = 4096;
 constexpr uint32_t CACHE_VERSION = 3;
 const char CACHE_MAGIC[8] = {'R', 'T', 'S', 'C', 'A', 'C', 'H', 'E'};
@@ -588,7 +590,8 @@ int rth_scene_cache_write(const char* path, const rth_config* c, const void* blo
     if (bytes < sizeof(rtl::BlobHeader)) return fail("rth_scene_cache_write: not a scene blob");
     if (c->output_file.size() >= sizeof(CacheHeader::output_file)) return fail("rth_scene_cache_write: output file name too long");
     std::vector<char> block(CACHE_HEADER_BYTES, 0);
-    CacheHeader h{};
+    CacheHeader h;
+    std::memset(&h, 0, sizeof(h));
     std::memcpy(h.magic, CACHE_MAGIC, 8);
     h.version = CACHE_VERSION; h.header_bytes = (uint32_t)CACHE_HEADER_BYTES;
     h.blob_bytes = bytes; h.blob_hash = hash64(blob, bytes);
@@ -633,8 +636,7 @@ rth_scene_cache* rth_scene_cache_open(const char* path) {
     else if (hash64((const char*)map + CACHE_HEADER_BYTES, (size_t)h.blob_bytes) != h.blob_hash) why = "scene cache: checksum mismatch";
     else {
         std::vector<char> block((const char*)map, (const char*)map + CACHE_HEADER_BYTES);
-        CacheHeader z = h; z.header_hash = 0;
-        std::memcpy(block.data(), &z, sizeof(z));
+        std::memset(block.data() + offsetof(CacheHeader, header_hash), 0, sizeof(h.header_hash));      // hashed with this field zero
         if (hash64(block.data(), block.size()) != h.header_hash) why = "scene cache: damaged header";
     }
     if (why) { munmap(map, (size_t)st.st_size); rte::set_error(why); return nullptr; }

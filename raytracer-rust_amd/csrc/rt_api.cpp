@@ -31,7 +31,13 @@
 
 namespace {
 
-struct RegionKey { uint32_t width, height, shard, nshards, tile_rows; uint64_t scene; };   // what the regions of a launch depend on
+struct RegionKey {                                           // what the regions of a launch depend on
+    uint32_t width, height, shard, nshards, tile_rows; uint64_t scene;
+    bool operator==(const RegionKey& o) const {
+        return width == o.width && height == o.height && shard == o.shard && nshards == o.nshards && tile_rows == o.tile_rows && scene == o.scene;
+    }
+    bool operator!=(const RegionKey& o) const { return !(*this == o); }
+};
 
 // A lane is a stream with the work buffers of the launches made on it.  Launches on one lane run in order;
 // launches on different lanes share nothing but the (read-only) scene and may overlap on the GPU, which is how
@@ -48,6 +54,7 @@ struct Lane {
     uint32_t* d_rows = nullptr; size_t rows_cap = 0;
     uint32_t* d_gathered = nullptr; size_t gathered_cap = 0;
     uint32_t* d_frame = nullptr; size_t frame_cap = 0;
+    hipEvent_t rows_ready = nullptr, gathered = nullptr;    // kernel of this lane done (for the gather) / this GPU's part in the gather done
 };
 constexpr int N_LANES = RT_LANES;
 
@@ -56,6 +63,10 @@ struct Device {
     Lane lanes[N_LANES];
     void* d_blob = nullptr; size_t blob_bytes = 0; bool blob_owned = false;
     DevScene dsc{};
+    // Every RCCL operation of this GPU's communicator is enqueued on this one stream, in the order the host issues them,
+    // whatever lane the frame belongs to: operations of one communicator then never meet on different streams, and the
+    // lanes' kernels and the reassembly are tied to it with events.
+    hipStream_t comm_stream = nullptr;
 };
 
 struct State {
@@ -73,6 +84,7 @@ struct State {
     // engine while the pieces that have arrived are copied on by the host's threads
     uint32_t* h_stage = nullptr; size_t stage_cap = 0;
     hipEvent_t piece_done[8] = {};
+    bool stage_by_copy = false;                             // RT_RENDER_STAGING=copy: rt_render on one GPU copies the finished frame instead of rendering into host memory
     uint64_t scene_generation = 0;                          // bumped whenever another scene becomes resident
 };
 State g;
@@ -102,6 +114,7 @@ int sync_lanes() {
     for (int d = g.ndev - 1; d >= 0; d--) {                  // ends with the first GPU current
         if (use(d)) return 1;
         for (Lane& l : g.devs[d].lanes) if (l.stream) HIP_TRY(hipStreamSynchronize(l.stream));
+        if (g.devs[d].comm_stream) HIP_TRY(hipStreamSynchronize(g.devs[d].comm_stream));
     }
     return 0;
 }
@@ -149,13 +162,13 @@ int scene_is_resident(const rtl::BlobHeader& h) {
             HIP_TRY(hipMalloc(&g.devs[d].d_blob, bytes));
             g.devs[d].blob_owned = true; g.devs[d].blob_bytes = bytes;
         }
-        NCCL_TRY(ncclGroupStart());
+        NCCL_TRY(ncclGroupStart());                                                              // (the upload itself has been waited for)
         for (int d = 0; d < g.ndev; d++)
-            NCCL_TRY(ncclBroadcast(g.devs[d].d_blob, g.devs[d].d_blob, bytes, ncclUint8, 0, g.comms[d], cur(d).stream));     // in place on every GPU
+            NCCL_TRY(ncclBroadcast(g.devs[d].d_blob, g.devs[d].d_blob, bytes, ncclUint8, 0, g.comms[d], g.devs[d].comm_stream));     // in place on every GPU
         NCCL_TRY(ncclGroupEnd());
         for (int d = g.ndev - 1; d >= 0; d--) {
             if (use(d)) return 1;
-            HIP_TRY(hipStreamSynchronize(cur(d).stream));
+            HIP_TRY(hipStreamSynchronize(g.devs[d].comm_stream));
             if (d > 0) point_at_blob(g.devs[d], h);
         }
     }
@@ -231,7 +244,7 @@ int plan_regions(Lane& lane, const rt_frame& fr, DevFrame* f) {
     f->regions_x = grid.nx; f->n_regions = grid.nx * grid.ny;
     if (f->n_regions > MAX_SORTED_REGIONS) return 0;          // (frames beyond 200 megapixels: raster order of regions)
     const RegionKey key = region_key(fr, f->shard, f->nshards, f->tile_rows);
-    if (!lane.region_key_valid || std::memcmp(&key, &lane.region_key, sizeof(key)) != 0) {
+    if (!lane.region_key_valid || key != lane.region_key) {
         if (reserve_regions(lane, f->n_regions)) return 1;
         // All costs equal: the sort leaves the regions in index order.
         HIP_TRY(hipMemsetAsync(lane.d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), lane.stream));
@@ -353,14 +366,26 @@ int render_frame_all(const rt_frame* frame, const uint32_t** d_frame, rt_stats* 
             if (enqueue_shard((int)d, frame, d, n, tile_rows, rows, stats != nullptr, count_work)) return 1;
         }
         if (n > 1) {
+            // The gather runs on the communicators' own streams: each waits for its GPU's kernel of this frame, and the
+            // reassembly on the first GPU's lane waits for the gather.
+            for (uint32_t d = 0; d < n; d++) {
+                if (use((int)d)) return 1;
+                HIP_TRY(hipEventRecord(cur((int)d).rows_ready, cur((int)d).stream));
+                HIP_TRY(hipStreamWaitEvent(g.devs[d].comm_stream, cur((int)d).rows_ready, 0));
+            }
             NCCL_TRY(ncclGroupStart());
             for (uint32_t d = 1; d < n; d++) {
                 const size_t count = (size_t)rt_shard_rows(H, d, n, tile_rows) * W;
                 if (count == 0) continue;
-                NCCL_TRY(ncclSend(cur((int)d).d_rows, count, ncclUint32, 0, g.comms[d], cur((int)d).stream));
-                NCCL_TRY(ncclRecv(l0.d_gathered + (size_t)d * stride * W, count, ncclUint32, (int)d, g.comms[0], l0.stream));
+                NCCL_TRY(ncclSend(cur((int)d).d_rows, count, ncclUint32, 0, g.comms[d], g.devs[d].comm_stream));
+                NCCL_TRY(ncclRecv(l0.d_gathered + (size_t)d * stride * W, count, ncclUint32, (int)d, g.comms[0], g.devs[0].comm_stream));
             }
             NCCL_TRY(ncclGroupEnd());
+            for (uint32_t d = n; d-- > 0;) {                 // later work of the lane (the reassembly; the next frame's kernel, which overwrites the rows) comes after the gather
+                if (use((int)d)) return 1;
+                HIP_TRY(hipEventRecord(cur((int)d).gathered, g.devs[d].comm_stream));
+                HIP_TRY(hipStreamWaitEvent(cur((int)d).stream, cur((int)d).gathered, 0));
+            }
         }
         if (use(0)) return 1;
         HIP_TRY(rtk_launch_assemble(l0.d_gathered, stride, n, tile_rows, W, H, l0.d_frame, l0.stream));
@@ -389,13 +414,18 @@ int init_devices(int first_device, int count) {
             HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreate(&l.ev0));
             HIP_TRY(hipEventCreate(&l.ev1));
+            HIP_TRY(hipEventCreateWithFlags(&l.rows_ready, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&l.gathered, hipEventDisableTiming));
             HIP_TRY(hipMalloc((void**)&l.d_counters, 16 * sizeof(unsigned long long)));
         }
+        HIP_TRY(hipStreamCreateWithFlags(&dev.comm_stream, hipStreamNonBlocking));
         HIP_TRY(rtk_noalloc_setup(dev.device));
     }
     HIP_TRY(hipSetDevice(first().device));
     g.lane = 0;
     g.inited = true;
+    const char* staging = std::getenv("RT_RENDER_STAGING");
+    g.stage_by_copy = staging && std::strcmp(staging, "copy") == 0;
     return 0;
 }
 
@@ -570,13 +600,26 @@ int rt_render(const rt_frame* frame, uint32_t* out_pixels, rt_stats* stats, int 
     size_t npix = (size_t)frame->width * frame->height;
     if (npix > g.stage_cap) {
         if (g.h_stage) { (void)hipHostFree(g.h_stage); g.h_stage = nullptr; g.stage_cap = 0; }
-        HIP_TRY(hipHostMalloc((void**)&g.h_stage, npix * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&g.h_stage, npix * sizeof(uint32_t), hipHostMallocMapped));
         g.stage_cap = npix;
     }
     rt_stats local{};
     const uint32_t* d_src = nullptr;
     if (g.have_comm) {
         if (render_frame_all(frame, &d_src, &local, count_work)) return 1;
+    } else if (!g.stage_by_copy) {
+        // One GPU: the kernel stores its pixels straight into the pinned staging buffer (host memory mapped into the GPU's
+        // address space), so the frame crosses the bus while it is being rendered, 4 bytes per pixel spread over the whole
+        // launch, instead of in one copy behind it.  What is left after the kernel is the host's copy into the caller's memory.
+        void* d_stage = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&d_stage, g.h_stage, 0));
+        if (render_shard(frame, 0, 1, RT_TILE_ROWS, (uint32_t*)d_stage, &local, count_work)) return 1;      // waits for the kernel (stats)
+        rtu::parallel_copy(out_pixels, g.h_stage, npix * sizeof(uint32_t));
+        if (stats) {
+            *stats = local;
+            stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        return 0;
     } else {
         if (grow(&g.d_out, &g.out_cap, npix)) return 1;
         if (render_shard(frame, 0, 1, RT_TILE_ROWS, g.d_out, &local, count_work)) return 1;
@@ -654,7 +697,7 @@ int rt_tile_costs_export(const rt_frame* frame, int gpu, uint32_t* costs, uint32
     if (!costs) return fail("rt_tile_costs_export: costs is NULL");
     if (use(gpu)) return 1;
     Lane& lane = cur(gpu);
-    if (!lane.region_key_valid || std::memcmp(&key, &lane.region_key, sizeof(key)) != 0)
+    if (!lane.region_key_valid || key != lane.region_key)
         return fail("rt_tile_costs_export: this frame has not been rendered on the current lane since the scene was uploaded");
     HIP_TRY(hipStreamSynchronize(lane.stream));
     HIP_TRY(hipMemcpy(costs, lane.d_region_last, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -695,6 +738,22 @@ int rt_synchronize(void) {
     return 0;
 }
 
+int rt_wait_event(void* hip_event) {
+    if (!g.inited) return fail("rt_init has not been called");
+    if (!hip_event) return fail("rt_wait_event: event is NULL");
+    if (use(0)) return 1;
+    HIP_TRY(hipStreamWaitEvent(cur().stream, (hipEvent_t)hip_event, 0));
+    return 0;
+}
+
+int rt_record_event(void* hip_event) {
+    if (!g.inited) return fail("rt_init has not been called");
+    if (!hip_event) return fail("rt_record_event: event is NULL");
+    if (use(0)) return 1;
+    HIP_TRY(hipEventRecord((hipEvent_t)hip_event, cur().stream));
+    return 0;
+}
+
 void rt_shutdown(void) {
     if (g.ndev == 0) { g = State(); return; }
     (void)sync_lanes();
@@ -716,8 +775,11 @@ void rt_shutdown(void) {
             if (l.d_frame) (void)hipFree(l.d_frame);
             if (l.ev0) (void)hipEventDestroy(l.ev0);
             if (l.ev1) (void)hipEventDestroy(l.ev1);
+            if (l.rows_ready) (void)hipEventDestroy(l.rows_ready);
+            if (l.gathered) (void)hipEventDestroy(l.gathered);
             if (l.stream) (void)hipStreamDestroy(l.stream);
         }
+        if (g.devs[d].comm_stream) (void)hipStreamDestroy(g.devs[d].comm_stream);
     }
     g = State();
 }

@@ -127,6 +127,8 @@ extern "C" {
     pub fn rt_copy_scene_blob(device_dst: *mut c_void, bytes: usize) -> c_int;
     pub fn rt_adopt_scene_blob(device_ptr: *mut c_void, bytes: usize) -> c_int;
     pub fn rt_synchronize() -> c_int;
+    pub fn rt_wait_event(hip_event: *mut c_void) -> c_int;
+    pub fn rt_record_event(hip_event: *mut c_void) -> c_int;
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_shutdown();
 }

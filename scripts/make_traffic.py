@@ -12,7 +12,12 @@ try:
     table = json.load(open(path))
 except (OSError, ValueError):
     table = {}
-entry = {"workload": workload, "kernel": "render_kernel", "source": os.path.relpath(sys.argv[2], ROOT) +
+import subprocess
+try:
+    commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h"], capture_output=True, text=True, timeout=10).stdout.strip()
+except (OSError, subprocess.SubprocessError):
+    commit = ""
+entry = {"workload": workload, "kernel": "render_kernel", "profiled_at_commit": commit or os.environ.get("RT_PROFILED_COMMIT", "unknown"), "source": os.path.relpath(sys.argv[2], ROOT) +
          ": rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum and the SQ counters in separate passes over "
          "scripts/render_once.py, means per launch; FETCH_SIZE (KiB) doubled as the gfx950 correction for 128-byte requests tallied "
          "at 64 bytes, WRITE_SIZE (KiB) taken as is"}

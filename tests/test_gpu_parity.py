@@ -245,6 +245,17 @@ def test_two_tracers_each_render_their_own_scene():
     for tracer, path in ((a, a_path), (b, b_path), (a, a_path)):
         diff, _ = rt.Image.compare(tracer.render(), rt.file_to_image(path[:-5] + ".png"))
         assert diff == 0, path
+    # a failed upload and a shutdown both leave no scene (or another one) resident: the tracers notice and upload again
+    with pytest.raises(rt.RtError):
+        rt.upload_scene_blob(np.zeros(1000, dtype=np.uint8))
+    diff, _ = rt.Image.compare(b.render(), rt.file_to_image(b_path[:-5] + ".png"))
+    assert diff == 0
+    rt.shutdown()
+    try:
+        diff, _ = rt.Image.compare(a.render(), rt.file_to_image(a_path[:-5] + ".png"))
+        assert diff == 0
+    finally:
+        rt.init(0)
 
 
 def test_tile_costs_carry_over_to_a_new_upload_and_change_no_pixel(tmp_path):
@@ -321,11 +332,11 @@ def test_sharded_tiles_reassemble_to_the_full_frame(nshards, tile_rows):
     W, H = frame.width, frame.height
     stride = max(rt.shard_rows(H, s, nshards, tile_rows) for s in range(nshards))
     gathered = torch.zeros((nshards, stride, W), dtype=torch.int32, device="cuda:0")
-    torch.cuda.synchronize()        # the fill runs on torch's stream, the library works on its own
+    rt.after_torch()                 # the fill runs on torch's stream: the library's lane waits for it (an event, no wait on the host)
     for s in range(nshards):
         rt.render_tiles(frame, s, nshards, gathered[s].data_ptr(), tile_rows=tile_rows)
     out = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
-    torch.cuda.synchronize()        # the fill runs on torch's stream, the library works on its own
+    rt.after_torch()                 # the fill runs on torch's stream: the library's lane waits for it (an event, no wait on the host)
     rt.assemble_tiles(gathered.data_ptr(), stride, nshards, W, H, out.data_ptr(), tile_rows=tile_rows)
     rt.synchronize()
     got = out.cpu().numpy().view(np.uint32)
@@ -340,7 +351,7 @@ def test_scene_blob_round_trip_replicates_the_scene():
     a = tracer.render().data.copy()
     ptr, nbytes = rt.scene_blob()
     copy = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
-    torch.cuda.synchronize()        # the fill runs on torch's stream, the library works on its own
+    rt.after_torch()                 # the fill runs on torch's stream: the library's lane waits for it (an event, no wait on the host)
     rt.copy_scene_blob(copy.data_ptr(), nbytes)
     rt.adopt_scene_blob(copy.data_ptr(), nbytes)
     b, _ = rt.render(cfg.frame())
@@ -418,7 +429,7 @@ def test_device_compare_equals_image_compare(size):
     stats, oracle_diff = O.compare(a, b)                                                # the oracle's restatement of mod.rs:54-89
     want_count = stats["ref_diff"]
     td = torch.full((h, w), -1, dtype=torch.int32, device="cuda:0")
-    torch.cuda.synchronize()        # the fill runs on torch's stream, the library works on its own
+    rt.after_torch()                 # the fill runs on torch's stream: the library's lane waits for it (an event, no wait on the host)
     got = rt.compare_frames(ta.data_ptr(), (w, h), tb.data_ptr(), (w, h), td.data_ptr())
     assert got == want_count
     assert np.array_equal(td.cpu().numpy().view(np.uint32), oracle_diff)
@@ -436,7 +447,7 @@ def test_device_compare_of_a_render_against_its_golden_image():
     rt.RayTracer.new(cfg)
     frame = cfg.frame()
     out = torch.zeros((frame.height, frame.width), dtype=torch.int32, device="cuda:0")
-    torch.cuda.synchronize()        # the fill runs on torch's stream, the library works on its own
+    rt.after_torch()                 # the fill runs on torch's stream: the library's lane waits for it (an event, no wait on the host)
     rt.render_tiles(frame, 0, 1, out.data_ptr())
     gold = rt.file_to_image(os.path.join(GOLDEN, "dragon3.png"))
     tg = torch.from_numpy(gold.pixels().view(np.int32)).to("cuda:0")
@@ -450,7 +461,7 @@ def test_device_rgb_packing_feeds_the_png_writer(size, tmp_path):
     px = np.random.default_rng(w).integers(0, 1 << 32, size=(h, w), dtype=np.uint32)
     tp = torch.from_numpy(px.view(np.int32)).to("cuda:0")
     rgb = torch.zeros(3 * w * h + 8, dtype=torch.uint8, device="cuda:0")
-    torch.cuda.synchronize()        # the fill runs on torch's stream, the library works on its own
+    rt.after_torch()                 # the fill runs on torch's stream: the library's lane waits for it (an event, no wait on the host)
     rt.pack_rgb(tp.data_ptr(), w, h, rgb.data_ptr())
     rt.synchronize()
     got = rgb.cpu().numpy()
@@ -675,13 +686,16 @@ def test_lanes_render_different_frames_at_once():
     want = [rt.render(f)[0] for f in frames]
     assert all(not np.array_equal(want[0], w) for w in want[1:])
     bufs = [torch.zeros((721, 1283), dtype=torch.int32, device="cuda:0") for _ in range(rt.LANES)]
-    torch.cuda.synchronize()        # the fill runs on torch's stream, the library works on its own
     try:
-        for _ in range(4):
+        for turn in range(4):
             for lane in range(rt.LANES):
                 rt.select_lane(lane)
+                if turn == 0:
+                    rt.after_torch()     # the fills run on torch's stream: every lane waits for them (an event, no wait on the host)
                 rt.render_tiles(frames[lane], 0, 1, bufs[lane].data_ptr())
-        torch.cuda.synchronize()
+        for lane in range(rt.LANES):
+            rt.select_lane(lane)
+            rt.before_torch()            # and torch's stream, which copies the frames back below, waits for every lane
         for lane in range(rt.LANES):
             assert np.array_equal(bufs[lane].cpu().numpy().view(np.uint32), want[lane]), lane
         with pytest.raises(rt.RtError, match="lanes are 0 .. 3"):

@@ -31,10 +31,10 @@ def test_compare_without_allocation_equals_compare():
     for w, h in ((1921, 1081), (333, 7), (5, 1)):                          # big first, then smaller ones
         ta, tb = _pair(rng, w, h, torch)
         want_diff = torch.full((h, w), -1, dtype=torch.int32, device="cuda:0")
-        torch.cuda.synchronize()                                           # the fill runs on torch's stream, the library works on its own
+        rt.after_torch()                                                   # the fills run on torch's stream: the library's lane waits for them (an event, no wait on the host)
         want = rt.compare_frames(ta.data_ptr(), (w, h), tb.data_ptr(), (w, h), want_diff.data_ptr())
         got_diff = torch.full((h, w), -2, dtype=torch.int32, device="cuda:0")
-        torch.cuda.synchronize()
+        rt.after_torch()
         rt.compare_frames_noalloc(ta.data_ptr(), (w, h), tb.data_ptr(), (w, h), count_dev.data_ptr(), got_diff.data_ptr())
         rt.synchronize()
         assert int(count_dev.item()) == want and want > 0
