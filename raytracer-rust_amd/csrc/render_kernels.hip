@@ -357,6 +357,57 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
     MARK("shadow_raybox");
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = point_light ? prune_limit(light_dist) : INF;
+#ifndef RT_SHADOW_PLAIN_LOOP
+    // The loop of closest_hit without the ordering: all lanes descend until each has a leaf in hand, and a lane that reaches its leaf
+    // early sets it aside and goes on towards its next one instead of idling, then tests both.  (What it descends on behalf of a leaf
+    // that turns out to hold an occluder is wasted; the lanes it no longer keeps waiting are worth more.)
+    uint32_t* low = stack;                              // as in closest_hit: the next free entry is low[128]
+    uint32_t held = 0;
+    for (;;) {
+        MARK("shadow_box");
+        while (!(cur & REF_LEAF)) {
+            const uint4* n = (const uint4*)((const char*)sc.nodes + cur);   // an inner reference is the pair's byte offset; 32 bits keep the address in one register
+            const uint4 c0 = n[0], c1 = n[1];
+            uint32_t below = low[64], below2 = low[0];
+            asm volatile("" : "+v"(below), "+v"(below2));       // keeps the reads here, under the node loads, instead of behind the box tests
+            float t0, t1;
+            bool h0 = slab(c0, rb, tlim, &t0);
+            bool h1 = slab(c1, rb, tlim, &t1);
+            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) { cnt->wave_node_iters++; cnt->wave_shadow_node_iters++; } }
+            const uint32_t r0 = c0.w, r1 = c1.w;
+            const bool both = h0 && h1, any = h0 || h1;
+            if (both) low[128] = r1;
+            const uint32_t next = h0 ? r0 : (h1 ? r1 : below);
+            const uint32_t under = both ? r1 : (any ? below : below2);
+            const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
+            held = take ? next : held;
+            cur = take ? under : next;
+            low = (uint32_t*)((char*)low + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));   // 256 bytes: one entry of every lane
+            if (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) == 0) break;
+        }
+        MARK("shadow_shape");
+        if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf
+            held = cur;
+            low -= 64; cur = low[128];
+        }
+        while (held != 0) {
+            uint32_t first = (held & ~REF_LEAF) >> 3, count = (held & 7u) + 1u;
+            uint32_t below = low[64];
+            asm volatile("" : "+v"(below));                     // read under the shape loads
+            for (uint32_t k = 0; k < count; k++) {
+                const float4* p = sc.tree + 3 * (size_t)(first + k);
+                if (COUNT) { cnt->prims++; if (first_active_lane()) { cnt->wave_prim_iters++; cnt->wave_shadow_prim_iters++; } }
+                if (occludes<SITE_SHADOW_TREE>(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
+            }
+            held = 0;
+            if ((cur & REF_LEAF) && cur != REF_EMPTY) {
+                held = cur;
+                low -= 64; cur = below;
+            }
+        }
+        if (cur == REF_EMPTY) break;
+    }
+#else
     uint32_t* low = stack;                              // as in closest_hit: the next free entry is low[128]
     while (cur != REF_EMPTY) {
         MARK("shadow_box");
@@ -388,6 +439,7 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
             low -= 64; cur = below;
         }
     }
+#endif
     return false;
 }
 
