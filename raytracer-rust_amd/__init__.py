@@ -499,9 +499,13 @@ def shard_rows(height, shard, nshards, tile_rows=TILE_ROWS):
     return int(lib().rt_shard_rows(height, shard, nshards, tile_rows))
 
 
-def render(frame, count_work=False):
-    """Whole frame into host memory: (pixels[H, W] uint32, stats dict)."""
-    out = np.empty((frame.height, frame.width), dtype=np.uint32)
+def render(frame, count_work=False, out=None):
+    """Whole frame into host memory: (pixels[H, W] uint32, stats dict).  `out`: a C-contiguous uint32 array of that shape to
+    render into (a caller that renders frame after frame keeps its buffer, as it would keep a Vec<u32>)."""
+    if out is None:
+        out = np.empty((frame.height, frame.width), dtype=np.uint32)
+    elif out.dtype != np.uint32 or out.shape != (frame.height, frame.width) or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous uint32 array of shape (height, width)")
     st = rt_stats()
     _check(lib().rt_render(C.byref(frame), out.ctypes.data, C.byref(st), int(bool(count_work))))
     return out, st.as_dict()

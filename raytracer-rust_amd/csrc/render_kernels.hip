@@ -468,8 +468,9 @@ __device__ __forceinline__ float specular_power(float base, float exponent, cons
     return base;
 #endif
 #ifndef RT_LIBRARY_POWF      // (for comparisons: everything through the device library)
-    if (rtpow::pow_specular_domain(base, exponent)) return rtpow::pow_specular(base, exponent, tables);
+    if (rtpow::pow_specular_domain(base, exponent)) { MARK("shade_pow_main_path"); return rtpow::pow_specular(base, exponent, tables); }
 #endif
+    MARK("shade_pow_off_the_main_path");
     if (__float_as_uint(base) == 0u && exponent > 0.0f && exponent < INF) return 0.0f;
     return powf(base, exponent);
 }

@@ -43,7 +43,7 @@ PHASE_PASSES = collections.OrderedDict([
     ("shadow_box", "shadow_box"),
     ("shadow_shape", "shadow_shape"), ("triangle_3", "shadow_shape:tree:triangle"), ("sphere_3", "shadow_shape:tree:sphere"),
     ("plane_3", "shadow_shape:tree:plane"), ("tested_3", "shadow_shape"), ("occluder_back_face_3", "never"), ("guards_3", "shadow_shape"),
-    ("shade", "shade"), ("shade_pow", "shade"), ("shade_sum", "shade"),
+    ("shade", "shade"), ("shade_pow", "shade"), ("shade_pow_main_path", "shade"), ("shade_pow_off_the_main_path", "never"), ("shade_sum", "shade"),
     ("level_end", "hit"), ("fold", "waves"), ("quantise", "waves"), ("epilogue", "waves"),
 ])
 # what the headline scene (final_avec_bonus.scene) holds: a plane in the always-tested list, triangles in the tree, point lights
@@ -104,14 +104,14 @@ def main():
     counts, copies = static_table(extra)
     units = ("valu", "salu", "vmem", "lds", "smem", "wait")
     passes = passes_of(json.load(open(args.counts)), args.lights) if args.counts else None
-    print(f"{'phase':16s} {'copies':>6s} " + " ".join(f"{u:>6s}" for u in units) + ("   passes(M)  valu(M)  share" if passes else ""))
+    print(f"{'phase':28s} {'copies':>6s} " + " ".join(f"{u:>6s}" for u in units) + ("   passes(M)  valu(M)  share" if passes else ""))
     total, rows = 0.0, []
     for phase in list(PHASE_PASSES) + [p for p in counts if p not in PHASE_PASSES]:
         if phase not in counts:
             continue
         n = max(copies[phase], 1)
         per = {u: counts[phase][u] / n for u in units}
-        row = f"{phase:16s} {n:6d} " + " ".join(f"{per[u]:6.1f}" for u in units)
+        row = f"{phase:28s} {n:6d} " + " ".join(f"{per[u]:6.1f}" for u in units)
         dyn = None
         if passes and phase in PHASE_PASSES:
             # loops: the marked stretch is one pass of the loop body (plus the few instructions between loop exit and the next mark)
