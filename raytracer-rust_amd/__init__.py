@@ -131,20 +131,29 @@ _lib = None
 
 
 def _share_hip_runtime_with_torch():
-    """PyTorch wheels bundle their own libamdhip64.so (same soname as /opt/rocm's).  Two HIP
-    runtimes in one process do not work (the second one finds no GPU), so when torch is
-    installed its copy is loaded first and librt_amd.so binds to it by soname.  Buffers and
-    streams can then be shared with torch (RCCL collectives on rendered tiles)."""
+    """PyTorch wheels bundle their own copies of the ROCm libraries (libamdhip64.so, librccl.so, the HSA runtime ..., same
+    sonames as /opt/rocm's).  Two HIP runtimes in one process do not work (the second one finds no GPU), so when torch is
+    installed it is imported before librt_amd.so is loaded, and the library binds to torch's copies by soname.  Buffers and
+    streams can then be shared with torch (RCCL collectives on rendered tiles).  Importing torch itself, rather than
+    loading its libamdhip64.so and librccl.so by path, matters: with only those two preloaded, a later `import torch`
+    brought the rest of its bundle in behind this library's dependencies and the process aborted at exit
+    ("double free or corruption") whenever torch was imported after rt_init.  RT_AMD_WITHOUT_TORCH=1 skips all of this
+    (a process that never touches torch then runs on /opt/rocm's libraries)."""
+    if os.environ.get("RT_AMD_WITHOUT_TORCH"):
+        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    for name in ("libamdhip64.so", "librccl.so"):          # (RCCL likewise: one copy per process, torch's when torch is there)
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
-        if os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    try:
+        import torch  # noqa: F401
+    except Exception:       # noqa: BLE001  (a broken torch must not keep the renderer from loading: fall back to its two libraries by path)
+        for name in ("libamdhip64.so", "librccl.so"):
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
 def lib():

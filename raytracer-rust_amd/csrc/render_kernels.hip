@@ -443,6 +443,92 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
     return false;
 }
 
+
+// Most rounds of 64 jobs a side-by-side round may take (0: never, every ray is traced by its own lane, kind after kind).
+#ifndef RT_SIDE_ROUNDS_MAX
+#define RT_SIDE_ROUNDS_MAX 2u
+#endif
+// One ray of either kind through the loop of closest_hit: a closest-hit ray as there, a shadow ray (any_hit) with the guards of
+// raytracer.rs:143-159 and an end at the first occluder.  For rounds in which the lanes of a wavefront carry rays of both kinds.
+// Result: *best for a closest-hit ray; the return value says whether a shadow ray found an occluder.
+template <bool COUNT>
+__device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool any_hit, bool hit_back, bool point_light, float light_dist,
+                                          uint32_t* stack, Best* best, Counters* cnt) {
+    best->t = INF; best->prim = NO_PRIM; best->order = 0xFFFFFFFFu;
+    bool occluded = false;
+    for (uint32_t i = 0; i < sc.n_list && !occluded; i++) {
+        const float4 q0 = uniform_load(sc.list, 3 * i), q1 = uniform_load(sc.list, 3 * i + 1), q2 = uniform_load(sc.list, 3 * i + 2);
+        float t;
+        if (COUNT) cnt->prims++;
+        if (!test_shape<SITE_CLOSEST_LIST>(q0, q1, q2, o, d, &t)) continue;
+        if (!any_hit) consider(best, t, LIST_FLAG | i, __float_as_uint(q1.w));
+        else occluded = !(t < 1e-6f) && !(hit_back && shape_back_face(q0, q1, q2, d)) && (!point_light || t < light_dist);
+    }
+    uint32_t cur = occluded ? REF_EMPTY : sc.root_ref;
+    if (cur == REF_EMPTY) return occluded;
+    const RayBox rb = make_raybox(sc, o, d);
+    float tlim = any_hit ? (point_light ? prune_limit(light_dist) : INF) : (best->prim == NO_PRIM ? INF : prune_limit(best->t));
+    uint32_t* low = stack;
+    uint32_t held = 0;
+    for (;;) {
+        while (!(cur & REF_LEAF)) {
+            const uint4* n = (const uint4*)((const char*)sc.nodes + cur);
+            const uint4 c0 = n[0], c1 = n[1];
+            uint32_t below = low[64], below2 = low[0];
+            asm volatile("" : "+v"(below), "+v"(below2));
+            float t0, t1;
+            bool h0 = slab(c0, rb, tlim, &t0);
+            bool h1 = slab(c1, rb, tlim, &t1);
+            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) { cnt->wave_node_iters++; if (any_hit) cnt->wave_shadow_node_iters++; } }
+            const uint32_t r0 = c0.w, r1 = c1.w;
+            const bool both = h0 && h1, any = h0 || h1, swap = t1 < t0;
+            const uint32_t far_child = swap ? r0 : r1;
+            if (both) low[128] = far_child;
+            const uint32_t next = both ? (swap ? r1 : r0) : (any ? (h0 ? r0 : r1) : below);
+            const uint32_t under = both ? far_child : (any ? below : below2);
+            const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
+            held = take ? next : held;
+            cur = take ? under : next;
+            low = (uint32_t*)((char*)low + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));
+            if (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) == 0) break;
+        }
+        if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {
+            held = cur;
+            low -= 64; cur = low[128];
+        }
+        while (held != 0) {
+            uint32_t first = (held & ~REF_LEAF) >> 3, count = (held & 7u) + 1u;
+            uint32_t below = low[64];
+            asm volatile("" : "+v"(below));
+            for (uint32_t k = 0; k < count && !occluded; k++) {
+                const float4* p = sc.tree + 3 * (size_t)(first + k);
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                float t;
+                if (COUNT) { cnt->prims++; if (first_active_lane()) { cnt->wave_prim_iters++; if (any_hit) cnt->wave_shadow_prim_iters++; } }
+                if (!test_shape<SITE_CLOSEST_TREE>(q0, q1, q2, o, d, &t)) continue;
+                if (!any_hit) {
+                    consider(best, t, first + k, __float_as_uint(q1.w));
+                    tlim = prune_limit(best->t);
+                } else {
+                    occluded = !(t < 1e-6f) && !(hit_back && shape_back_face(q0, q1, q2, d)) && (!point_light || t < light_dist);
+                }
+            }
+            held = 0;
+            if (occluded) { cur = REF_EMPTY; break; }
+            if ((cur & REF_LEAF) && cur != REF_EMPTY) {
+                held = cur;
+                low -= 64; cur = below;
+            }
+        }
+        if (cur == REF_EMPTY) break;
+    }
+    return occluded;
+}
+
+// The value `v` has in lane `from` (every lane names its own source).
+__device__ __forceinline__ float pull(float v, uint32_t from) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(from << 2), __float_as_int(v))); }
+__device__ __forceinline__ uint32_t pull(uint32_t v, uint32_t from) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); }
+
 __device__ __forceinline__ uint32_t quantise(V3 c) {                                             // raytracer.rs:85-91
     uint32_t r = (uint32_t)roundf(fminf(fmaxf(c.x, 0.0f), 1.0f) * 255.0f);
     uint32_t g = (uint32_t)roundf(fminf(fmaxf(c.y, 0.0f), 1.0f) * 255.0f);
@@ -509,12 +595,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
     stack[0] = REF_EMPTY; stack[64] = REF_EMPTY;
     Counters cnt = {};
     const bool live = x < f.width && r < f.local_rows;
-    if (live) {
+    // The wavefront walks the path levels together (the level is the same number in every lane); `alive` says whether this lane's
+    // path still goes on.  Once so few paths are left that the shadow rays of every live hit AND the closest-hit ray of its next
+    // level fit the 64 lanes, they are traced side by side, one ray per lane, by whoever has a lane to spare: those rays
+    // depend on nothing but the hit.  The round lasts as long as its slowest ray instead of the slowest closest-hit ray plus the
+    // slowest ray to each light.  Each job rebuilds its ray from the owner's hit with the owner's arithmetic; the owner shades
+    // with the answers, light after light in the reference's order.
+    {
         const uint32_t y = frame_row(f, r);
         const size_t pix = (size_t)r * f.width + x;
         const size_t npix = (size_t)f.local_rows * f.width;
-
-        // raytracer.rs:61-66
         MARK("raygen");
         float b = (f.ph * (f.h2 - ((float)y + 0.5f))) / f.h2;
         float a = (f.pw * (((float)x + 0.5f) - f.w2)) / f.w2;
@@ -522,101 +612,178 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
         V3 d = vnormalize(vadd(vadd(vscale(right, a), vscale(up, b)), cv));
         V3 o = v3(f.pos);
         const V3 ambient = v3(f.ambient);
+        const uint32_t jobs_per_hit = sc.n_lights + 1u;
 
         V3 cur = v3(0.0f, 0.0f, 0.0f);   // colour returned by the deepest level
-        uint32_t depth = 0;
-        for (;;) {
-            Best best;
-            if (COUNT && first_active_lane()) cnt.wave_closest++;
-            closest_hit<COUNT>(sc, o, d, stack, &best, &cnt);
+        bool alive = live;
+        uint32_t levels = 0;             // reflection records this lane has left behind
+        Best next = {0.0f, NO_PRIM, 0u};
+        bool have_next = false;          // (the same in every lane) the closest hit of this level was found in the round before
+        for (uint32_t depth = 0; __builtin_amdgcn_ballot_w64(alive) != 0; depth++) {
+            Best best = next;
+            if (alive && !have_next) {
+                if (COUNT && first_active_lane()) cnt.wave_closest++;
+                closest_hit<COUNT>(sc, o, d, stack, &best, &cnt);
+            }
             MARK("hit");
-            if (best.prim == NO_PRIM) { cur = v3(0.0f, 0.0f, 0.0f); break; }                    // raytracer.rs:199-201
-
-            // Rebuild the reference's Intersection for the winner (shape.rs:84-95, 122-132, 178-191).
-            if (COUNT && first_active_lane()) cnt.wave_hit++;
-            const float4* rec = (best.prim & LIST_FLAG) ? sc.list + 3 * (size_t)(best.prim & ~LIST_FLAG) : sc.tree + 3 * (size_t)best.prim;
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-            const uint32_t km = __float_as_uint(q0.w), kind = km & 3u, mat = km >> 2;
-            V3 point = vadd(o, vscale(d, best.t));
-            V3 normal; bool back = false;
-            if (kind == KIND_TRIANGLE) {
-                MARK("hit_triangle");
-                normal = vnormalize(vcross(v3(q1), v3(q2)));      // the record holds the edges
-                back = vdot(normal, d) > 0.0f;
-            } else if (kind == KIND_SPHERE) {
-                MARK("hit_sphere");
-                normal = vnormalize(vsub(point, v3(q0)));
-            } else {
-                MARK("hit_plane");
-                normal = v3(q2);
-            }
-            MARK("hit_material");
-            const float4 m0 = sc.mats[2 * (size_t)mat], m1 = sc.mats[2 * (size_t)mat + 1];
-            const V3 diffuse_color = v3(m0), specular_color = v3(m1);
-            const float shininess = m0.w;
-
-            V3 acc = v3(0.0f, 0.0f, 0.0f);
-            const V3 shadow_origin = vadd(point, vscale(normal, 1e-6f));                        // raytracer.rs:133
-            for (uint32_t li = 0; li < sc.n_lights; li++) {                                      // raytracer.rs:126-179
-                MARK("light");
-                const float4 l0 = uniform_load(sc.lights, 2 * li), l1 = uniform_load(sc.lights, 2 * li + 1);
-                const bool point_light = l0.w == 0.0f;
-                V3 light_dir; float light_dist = 0.0f;
-                if (point_light) {
-                    MARK("light_point");
-                    V3 to_light = vsub(v3(l0), point);
-                    light_dir = vnormalize(to_light);
-                    light_dist = vnorm(to_light);
+            if (alive && best.prim == NO_PRIM) { cur = v3(0.0f, 0.0f, 0.0f); alive = false; }   // raytracer.rs:199-201
+            V3 point = v3(0.0f, 0.0f, 0.0f), normal = point, shadow_origin = point, diffuse_color = point, specular_color = point;
+            float shininess = 0.0f;
+            uint32_t mat = 0;
+            bool back = false, goes_on = false;
+            if (alive) {
+                // Rebuild the reference's Intersection for the winner (shape.rs:84-95, 122-132, 178-191).
+                if (COUNT && first_active_lane()) cnt.wave_hit++;
+                const float4* rec = (best.prim & LIST_FLAG) ? sc.list + 3 * (size_t)(best.prim & ~LIST_FLAG) : sc.tree + 3 * (size_t)best.prim;
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                const uint32_t km = __float_as_uint(q0.w), kind = km & 3u;
+                mat = km >> 2;
+                point = vadd(o, vscale(d, best.t));
+                if (kind == KIND_TRIANGLE) {
+                    normal = vnormalize(vcross(v3(q1), v3(q2)));      // the record holds the edges
+                    back = vdot(normal, d) > 0.0f;
+                } else if (kind == KIND_SPHERE) {
+                    normal = vnormalize(vsub(point, v3(q0)));
                 } else {
-                    MARK("light_directional");
-                    light_dir = v3(l0);
+                    normal = v3(q2);
                 }
-                MARK("light_horizon");
-                if (COUNT) cnt.shadow++;
-                float n_dot_l = fmaxf(vdot(normal, light_dir), 0.0f);
-                // A light at or below the horizon of the surface adds (diffuse*0 + specular*0) (*) colour = +0
-                // whether or not it is occluded (unless shininess == 1, where the factor ignores n.l), so
-                // its shadow ray need not be traced.  Only valid while every factor is finite.
-                if (sc.finite_shading && n_dot_l == 0.0f && shininess != 1.0f) continue;
-                if (COUNT && first_active_lane()) cnt.wave_shadow++;
-                if (in_shadow<COUNT>(sc, shadow_origin, light_dir, back, point_light, light_dist, stack, &cnt)) continue;
-                MARK("shade");
-                if (COUNT && first_active_lane()) cnt.wave_shade++;
-                V3 diffuse = vscale(diffuse_color, n_dot_l);
-                V3 view_dir = vneg(d);
-                V3 half_vector = vnormalize(vadd(light_dir, view_dir));
-                float n_dot_h = fmaxf(vdot(normal, half_vector), 0.0f);
-                float factor;
-                if (shininess == 1.0f) factor = n_dot_h;
-                else if (shininess == 0.0f) factor = n_dot_l > 0.0f ? n_dot_h : 0.0f;
-                else { MARK("shade_pow"); factor = n_dot_l > 0.0f ? specular_power(n_dot_h, shininess, pow_tables) : 0.0f; }
-                MARK("shade_sum");
-                V3 specular = vscale(specular_color, factor);
-                acc = vadd(acc, vcmul(vadd(diffuse, specular), v3(l1)));
+                const float4 m0 = sc.mats[2 * (size_t)mat], m1 = sc.mats[2 * (size_t)mat + 1];
+                diffuse_color = v3(m0); specular_color = v3(m1);
+                shininess = m0.w;
+                shadow_origin = vadd(point, vscale(normal, 1e-6f));                             // raytracer.rs:133
+                const bool reflective = specular_color.x > 0.0f || specular_color.y > 0.0f || specular_color.z > 0.0f;
+                goes_on = reflective && depth + 1u < f.maxdepth;                                // raytracer.rs:187
             }
-            MARK("level_end");
-            V3 local = vadd(acc, ambient);                                                       // raytracer.rs:181
-            bool reflective = specular_color.x > 0.0f || specular_color.y > 0.0f || specular_color.z > 0.0f;
-            if (!(reflective && depth + 1u < f.maxdepth)) { cur = local; break; }                // raytracer.rs:187
-            const float4 record = make_float4(local.x, local.y, local.z, __uint_as_float(mat));
-            if (depth < lds_levels) fold_lds[depth * 64u] = record;
-            else fold[(size_t)(depth - lds_levels) * npix + pix] = record;
-            float k2 = 2.0f * vdot(d, normal);                                                   // raytracer.rs:188-190
-            d = vsub(d, vscale(normal, k2));
-            o = shadow_origin;
-            depth++;
-            if (COUNT) cnt.secondary++;
+
+            // ---- the rays that depend on this hit only, side by side when they fit
+            const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
+            const uint32_t n_alive = (uint32_t)__popcll(alive_mask);
+            // worth it when the jobs take fewer rounds of 64 than the one-after-the-other way takes passes (one per light and one for the next level)
+            const uint32_t n_jobs = n_alive * jobs_per_hit, n_rounds = (n_jobs + 63u) >> 6;
+            const bool side_by_side = n_alive != 0u && n_rounds <= RT_SIDE_ROUNDS_MAX && n_rounds < jobs_per_hit && sc.n_lights <= 31u;      // the same in every lane
+            uint32_t lit = 0;            // side by side: bit li set = light li is not occluded
+            have_next = false;
+            if (side_by_side) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(alive_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)alive_mask, 0u));
+                // lane numbers of the live lanes, packed from lane 0 upwards (the others from lane 63 downwards)
+                const uint32_t table = (uint32_t)__builtin_amdgcn_ds_permute((int)((alive ? rank : 63u - (lane - rank)) << 2), (int)lane);
+                const uint32_t first_job = rank * jobs_per_hit;                                 // (meaningful in live lanes)
+                for (uint32_t round = 0; round < n_rounds; round++) {
+                    const uint32_t job = round * 64u + lane, hit_of_job = job / jobs_per_hit, kind = job - hit_of_job * jobs_per_hit;
+                    const bool mine = job < n_jobs;
+                    const uint32_t owner = pull(table, mine ? hit_of_job : 0u);
+                    const V3 at = v3(pull(point.x, owner), pull(point.y, owner), pull(point.z, owner));
+                    const V3 nrm = v3(pull(normal.x, owner), pull(normal.y, owner), pull(normal.z, owner));
+                    const V3 dir_in = v3(pull(d.x, owner), pull(d.y, owner), pull(d.z, owner));
+                    const uint32_t flags = pull((back ? 1u : 0u) | (goes_on ? 2u : 0u), owner);
+                    const float shin = pull(shininess, owner);
+                    const bool shadow_job = kind < sc.n_lights;
+                    bool need = mine, point_light = false;
+                    float light_dist = 0.0f;
+                    V3 ray_dir;
+                    if (shadow_job) {
+                        const float4 l0 = sc.lights[2 * (size_t)(mine ? kind : 0u)];
+                        point_light = l0.w == 0.0f;
+                        if (point_light) {
+                            V3 to_light = vsub(v3(l0), at);
+                            ray_dir = vnormalize(to_light);
+                            light_dist = vnorm(to_light);
+                        } else {
+                            ray_dir = v3(l0);
+                        }
+                        const float n_dot_l = fmaxf(vdot(nrm, ray_dir), 0.0f);
+                        if (sc.finite_shading && n_dot_l == 0.0f && shin != 1.0f) need = false; // contributes nothing either way (see the light loop below)
+                    } else {
+                        need = need && (flags & 2u) != 0u;
+                        const float k2 = 2.0f * vdot(dir_in, nrm);                              // raytracer.rs:188-190
+                        ray_dir = vsub(dir_in, vscale(nrm, k2));
+                    }
+                    Best found = {0.0f, NO_PRIM, 0u};
+                    bool occluded = false;
+                    if (need) {
+                        if (COUNT && first_active_lane()) cnt.wave_shadow++;
+                        occluded = trace_job<COUNT>(sc, vadd(at, vscale(nrm, 1e-6f)), ray_dir, shadow_job, (flags & 1u) != 0u, point_light, light_dist, stack, &found, &cnt);
+                    }
+                    const uint32_t word = shadow_job ? ((need && !occluded) ? 1u : 0u) : found.prim;
+                    // every live lane collects the answers of its jobs that were in this round
+                    for (uint32_t li = 0; li < sc.n_lights; li++) {
+                        const uint32_t answer = pull(word, (first_job + li) & 63u);
+                        if (((first_job + li) >> 6) == round) lit |= answer << li;
+                    }
+                    const uint32_t next_prim = pull(word, (first_job + sc.n_lights) & 63u);
+                    const float next_t = pull(found.t, (first_job + sc.n_lights) & 63u);
+                    if (((first_job + sc.n_lights) >> 6) == round) { next.prim = next_prim; next.t = next_t; }
+                }
+                have_next = true;
+            }
+
+            if (alive) {
+                V3 acc = v3(0.0f, 0.0f, 0.0f);
+                for (uint32_t li = 0; li < sc.n_lights; li++) {                                  // raytracer.rs:126-179
+                    MARK("light");
+                    const float4 l0 = uniform_load(sc.lights, 2 * li), l1 = uniform_load(sc.lights, 2 * li + 1);
+                    const bool point_light = l0.w == 0.0f;
+                    V3 light_dir; float light_dist = 0.0f;
+                    if (point_light) {
+                        V3 to_light = vsub(v3(l0), point);
+                        light_dir = vnormalize(to_light);
+                        light_dist = vnorm(to_light);
+                    } else {
+                        light_dir = v3(l0);
+                    }
+                    if (COUNT) cnt.shadow++;
+                    float n_dot_l = fmaxf(vdot(normal, light_dir), 0.0f);
+                    // A light at or below the horizon of the surface adds (diffuse*0 + specular*0) (*) colour = +0
+                    // whether or not it is occluded (unless shininess == 1, where the factor ignores n.l), so
+                    // its shadow ray need not be traced.  Only valid while every factor is finite.
+                    if (sc.finite_shading && n_dot_l == 0.0f && shininess != 1.0f) continue;
+                    if (side_by_side) {
+                        if (!((lit >> li) & 1u)) continue;
+                    } else {
+                        if (COUNT && first_active_lane()) cnt.wave_shadow++;
+                        if (in_shadow<COUNT>(sc, shadow_origin, light_dir, back, point_light, light_dist, stack, &cnt)) continue;
+                    }
+                    MARK("shade");
+                    if (COUNT && first_active_lane()) cnt.wave_shade++;
+                    V3 diffuse = vscale(diffuse_color, n_dot_l);
+                    V3 view_dir = vneg(d);
+                    V3 half_vector = vnormalize(vadd(light_dir, view_dir));
+                    float n_dot_h = fmaxf(vdot(normal, half_vector), 0.0f);
+                    float factor;
+                    if (shininess == 1.0f) factor = n_dot_h;
+                    else if (shininess == 0.0f) factor = n_dot_l > 0.0f ? n_dot_h : 0.0f;
+                    else { MARK("shade_pow"); factor = n_dot_l > 0.0f ? specular_power(n_dot_h, shininess, pow_tables) : 0.0f; }
+                    MARK("shade_sum");
+                    V3 specular = vscale(specular_color, factor);
+                    acc = vadd(acc, vcmul(vadd(diffuse, specular), v3(l1)));
+                }
+                MARK("level_end");
+                V3 local = vadd(acc, ambient);                                                   // raytracer.rs:181
+                if (!goes_on) { cur = local; alive = false; }
+                else {
+                    const float4 record = make_float4(local.x, local.y, local.z, __uint_as_float(mat));
+                    if (depth < lds_levels) fold_lds[depth * 64u] = record;
+                    else fold[(size_t)(depth - lds_levels) * npix + pix] = record;
+                    levels = depth + 1u;
+                    float k2 = 2.0f * vdot(d, normal);                                           // raytracer.rs:188-190
+                    d = vsub(d, vscale(normal, k2));
+                    o = shadow_origin;
+                    if (COUNT) cnt.secondary++;
+                }
+            }
         }
-        // Backward fold: final_k = local_k + specular_k (*) final_{k+1}                           raytracer.rs:194-195
-        MARK("fold");
-        while (depth > 0) {
-            depth--;
-            const float4 rec = depth < lds_levels ? fold_lds[depth * 64u] : fold[(size_t)(depth - lds_levels) * npix + pix];
-            const float4 m1 = sc.mats[2 * (size_t)__float_as_uint(rec.w) + 1];
-            cur = vadd(v3(rec), vcmul(v3(m1), cur));
+        if (live) {
+            // Backward fold: final_k = local_k + specular_k (*) final_{k+1}                       raytracer.rs:194-195
+            MARK("fold");
+            while (levels > 0) {
+                levels--;
+                const float4 rec = levels < lds_levels ? fold_lds[levels * 64u] : fold[(size_t)(levels - lds_levels) * npix + pix];
+                const float4 m1 = sc.mats[2 * (size_t)__float_as_uint(rec.w) + 1];
+                cur = vadd(v3(rec), vcmul(v3(m1), cur));
+            }
+            MARK("quantise");
+            out[pix] = quantise(cur);
         }
-        MARK("quantise");
-        out[pix] = quantise(cur);
     }
     MARK("epilogue");
     if (f.region_cost && lane == 0) atomicMax(&f.region_cost[region], (uint32_t)(__builtin_amdgcn_s_memrealtime() - started));
