@@ -93,9 +93,11 @@ typedef struct rt_stats {
     uint64_t box_passes;     /* instrumented runs: wavefront-level passes of the box-test loop; lane use =
                                 nodes_visited / 2 / (64 * box_passes)                                   */
     uint64_t shape_passes;   /* the same for the shape-test loop: prims_tested / (64 * shape_passes)  */
-    uint64_t phase_passes[6];/* instrumented runs: wavefront-level passes through the phases of a path level: closest-hit
-                                searches started, hits shaded, shadow rays traced, lights shaded (not in shadow), and the
-                                share of shadow rays in box_passes and in shape_passes                            */
+    uint64_t phase_passes[9];/* instrumented runs: wavefront-level passes through the phases of a path level: closest-hit
+                                searches started, hits shaded, shadow rays traced light by light, lights shaded (not in
+                                shadow), the share of those shadow rays in box_passes and in shape_passes, side-by-side
+                                rounds (shadow rays and next closest-hit rays of few live paths, one per lane), and their
+                                share in box_passes and in shape_passes                                            */
     double kernel_ms;        /* render kernel(s), HIP events on the library's stream        */
     double total_ms;         /* whole call, host clock                                      */
 } rt_stats;

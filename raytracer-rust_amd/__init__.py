@@ -50,7 +50,7 @@ class rt_scene(C.Structure):
 class rt_stats(C.Structure):
     _fields_ = [("primary", C.c_uint64), ("shadow", C.c_uint64), ("secondary", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
-                ("box_passes", C.c_uint64), ("shape_passes", C.c_uint64), ("phase_passes", C.c_uint64 * 6),
+                ("box_passes", C.c_uint64), ("shape_passes", C.c_uint64), ("phase_passes", C.c_uint64 * 9),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
 
     def as_dict(self):

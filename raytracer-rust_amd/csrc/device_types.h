@@ -38,7 +38,7 @@ struct DevFrame {
 
 
 constexpr uint32_t MAX_SORTED_REGIONS = 4096;
-#define RT_N_COUNTERS 12                         // 64-bit work counters of an instrumented launch (render_kernels.hip, rt_api.cpp)   // what one workgroup sorts in LDS
+#define RT_N_COUNTERS 15                         // 64-bit work counters of an instrumented launch (render_kernels.hip, rt_api.cpp)   // what one workgroup sorts in LDS
 
 // Region size for a launch of tiles_x x tiles_y pixel tiles: 0 = row-major tile order.
 // Frames of fewer than 2048 tiles keep row-major order; otherwise the smallest regions (from 8x8 tiles up) that

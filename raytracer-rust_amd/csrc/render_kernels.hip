@@ -81,7 +81,8 @@ __device__ __forceinline__ float4 uniform_load(const float4* base, uint32_t inde
 struct Counters {
     uint32_t nodes, prims, shadow, secondary, wave_node_iters, wave_prim_iters;
     uint32_t wave_closest, wave_hit, wave_shadow, wave_shade;      // wavefront-level passes through the phases of a path level
-    uint32_t wave_shadow_node_iters, wave_shadow_prim_iters;       // the share of shadow rays in wave_node_iters / wave_prim_iters
+    uint32_t wave_shadow_node_iters, wave_shadow_prim_iters;       // the share of shadow rays (traced light by light) in wave_node_iters / wave_prim_iters
+    uint32_t wave_rounds, wave_round_node_iters, wave_round_prim_iters;   // side-by-side rounds, and their share in wave_node_iters / wave_prim_iters
 };
 
 // Diagnostic builds (-DRT_MARKS, compiled to assembly only) leave comments in the instruction stream, from which
@@ -456,6 +457,7 @@ __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool a
                                           uint32_t* stack, Best* best, Counters* cnt) {
     best->t = INF; best->prim = NO_PRIM; best->order = 0xFFFFFFFFu;
     bool occluded = false;
+    MARK("round_list");
     for (uint32_t i = 0; i < sc.n_list && !occluded; i++) {
         const float4 q0 = uniform_load(sc.list, 3 * i), q1 = uniform_load(sc.list, 3 * i + 1), q2 = uniform_load(sc.list, 3 * i + 2);
         float t;
@@ -466,11 +468,13 @@ __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool a
     }
     uint32_t cur = occluded ? REF_EMPTY : sc.root_ref;
     if (cur == REF_EMPTY) return occluded;
+    MARK("round_raybox");
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = any_hit ? (point_light ? prune_limit(light_dist) : INF) : (best->prim == NO_PRIM ? INF : prune_limit(best->t));
     uint32_t* low = stack;
     uint32_t held = 0;
     for (;;) {
+        MARK("round_box");
         while (!(cur & REF_LEAF)) {
             const uint4* n = (const uint4*)((const char*)sc.nodes + cur);
             const uint4 c0 = n[0], c1 = n[1];
@@ -479,7 +483,7 @@ __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool a
             float t0, t1;
             bool h0 = slab(c0, rb, tlim, &t0);
             bool h1 = slab(c1, rb, tlim, &t1);
-            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) { cnt->wave_node_iters++; if (any_hit) cnt->wave_shadow_node_iters++; } }
+            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) { cnt->wave_node_iters++; cnt->wave_round_node_iters++; } }
             const uint32_t r0 = c0.w, r1 = c1.w;
             const bool both = h0 && h1, any = h0 || h1, swap = t1 < t0;
             const uint32_t far_child = swap ? r0 : r1;
@@ -492,6 +496,7 @@ __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool a
             low = (uint32_t*)((char*)low + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));
             if (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) == 0) break;
         }
+        MARK("round_shape");
         if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {
             held = cur;
             low -= 64; cur = low[128];
@@ -504,7 +509,7 @@ __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool a
                 const float4* p = sc.tree + 3 * (size_t)(first + k);
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2];
                 float t;
-                if (COUNT) { cnt->prims++; if (first_active_lane()) { cnt->wave_prim_iters++; if (any_hit) cnt->wave_shadow_prim_iters++; } }
+                if (COUNT) { cnt->prims++; if (first_active_lane()) { cnt->wave_prim_iters++; cnt->wave_round_prim_iters++; } }
                 if (!test_shape<SITE_CLOSEST_TREE>(q0, q1, q2, o, d, &t)) continue;
                 if (!any_hit) {
                     consider(best, t, first + k, __float_as_uint(q1.w));
@@ -669,6 +674,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
                 const uint32_t table = (uint32_t)__builtin_amdgcn_ds_permute((int)((alive ? rank : 63u - (lane - rank)) << 2), (int)lane);
                 const uint32_t first_job = rank * jobs_per_hit;                                 // (meaningful in live lanes)
                 for (uint32_t round = 0; round < n_rounds; round++) {
+                    MARK("round_setup");
+                    if (COUNT && first_active_lane()) cnt.wave_rounds++;
                     const uint32_t job = round * 64u + lane, hit_of_job = job / jobs_per_hit, kind = job - hit_of_job * jobs_per_hit;
                     const bool mine = job < n_jobs;
                     const uint32_t owner = pull(table, mine ? hit_of_job : 0u);
@@ -701,9 +708,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
                     Best found = {0.0f, NO_PRIM, 0u};
                     bool occluded = false;
                     if (need) {
-                        if (COUNT && first_active_lane()) cnt.wave_shadow++;
                         occluded = trace_job<COUNT>(sc, vadd(at, vscale(nrm, 1e-6f)), ray_dir, shadow_job, (flags & 1u) != 0u, point_light, light_dist, stack, &found, &cnt);
                     }
+                    MARK("round_collect");
                     const uint32_t word = shadow_job ? ((need && !occluded) ? 1u : 0u) : found.prim;
                     // every live lane collects the answers of its jobs that were in this round
                     for (uint32_t li = 0; li < sc.n_lights; li++) {
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
     if (COUNT) {
         unsigned long long v[RT_N_COUNTERS] = {cnt.nodes, cnt.prims, cnt.shadow, cnt.secondary, cnt.wave_node_iters, cnt.wave_prim_iters,
                                                cnt.wave_closest, cnt.wave_hit, cnt.wave_shadow, cnt.wave_shade, cnt.wave_shadow_node_iters,
-                                               cnt.wave_shadow_prim_iters};
+                                               cnt.wave_shadow_prim_iters, cnt.wave_rounds, cnt.wave_round_node_iters, cnt.wave_round_prim_iters};
         for (int k = 0; k < RT_N_COUNTERS; k++) {
             unsigned long long s = v[k];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);

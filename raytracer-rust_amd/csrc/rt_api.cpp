@@ -321,7 +321,7 @@ int collect_stats(int d, const rt_frame* frame, uint32_t shard, uint32_t nshards
         HIP_TRY(hipMemcpy(c, lane.d_counters, sizeof(c), hipMemcpyDeviceToHost));
         stats->nodes_visited += c[0]; stats->prims_tested += c[1]; stats->shadow += c[2]; stats->secondary += c[3];
         stats->box_passes += c[4]; stats->shape_passes += c[5];
-        for (int k = 0; k < 6; k++) stats->phase_passes[k] += c[6 + k];
+        for (int k = 0; k < 9; k++) stats->phase_passes[k] += c[6 + k];
     }
     return 0;
 }

@@ -57,7 +57,7 @@ pub struct rt_stats {
     pub prims_tested: u64,
     pub box_passes: u64,
     pub shape_passes: u64,
-    pub phase_passes: [u64; 6],
+    pub phase_passes: [u64; 9],
     pub kernel_ms: f64,
     pub total_ms: f64,
 }
