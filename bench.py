@@ -285,7 +285,8 @@ def main():
         """A frame in device memory of the first GPU (raw pointer) copied to the host."""
         import ctypes
         host = np.empty((H, W), dtype=np.uint32)
-        hip = ctypes.CDLL(None)      # the HIP runtime already loaded into the process
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")      # the HIP runtime already loaded into the process (torch's copy)
+        hip = ctypes.CDLL(bundled if os.path.exists(bundled) else "libamdhip64.so")
         assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(host.nbytes), 2) == 0      # device to host
         return host
 

@@ -94,7 +94,7 @@ struct Counters {
 #define MARK(name)
 #define MARK_AT(name, site)
 #endif
-enum Site { SITE_CLOSEST_LIST, SITE_CLOSEST_TREE, SITE_SHADOW_LIST, SITE_SHADOW_TREE };
+enum Site { SITE_CLOSEST_LIST, SITE_CLOSEST_TREE, SITE_SHADOW_LIST, SITE_SHADOW_TREE, SITE_ROUND_LIST, SITE_ROUND_TREE };
 
 // True on exactly one of the currently active lanes.
 __device__ __forceinline__ bool first_active_lane() { return (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1); }
@@ -449,6 +449,18 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
 #ifndef RT_SIDE_ROUNDS_MAX
 #define RT_SIDE_ROUNDS_MAX 2u
 #endif
+// The guards of raytracer.rs:143-159 for a candidate that the exact test accepts at distance t.
+template <int SITE>
+__device__ __forceinline__ bool occludes_at(const float4 q0, const float4 q1, const float4 q2, V3 d, float t, bool hit_back, bool point_light, float light_dist) {
+    bool blocks = !(t < 1e-6f) && (!point_light || t < light_dist);
+    if (blocks && hit_back) {
+        MARK_AT("occluder_back_face", SITE);
+        blocks = !shape_back_face(q0, q1, q2, d);
+    }
+    MARK_AT("guards", SITE);
+    return blocks;
+}
+
 // One ray of either kind through the loop of closest_hit: a closest-hit ray as there, a shadow ray (any_hit) with the guards of
 // raytracer.rs:143-159 and an end at the first occluder.  For rounds in which the lanes of a wavefront carry rays of both kinds.
 // Result: *best for a closest-hit ray; the return value says whether a shadow ray found an occluder.
@@ -462,9 +474,10 @@ __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool a
         const float4 q0 = uniform_load(sc.list, 3 * i), q1 = uniform_load(sc.list, 3 * i + 1), q2 = uniform_load(sc.list, 3 * i + 2);
         float t;
         if (COUNT) cnt->prims++;
-        if (!test_shape<SITE_CLOSEST_LIST>(q0, q1, q2, o, d, &t)) continue;
+        if (!test_shape<SITE_ROUND_LIST>(q0, q1, q2, o, d, &t)) continue;
+        MARK_AT("tested", SITE_ROUND_LIST);
         if (!any_hit) consider(best, t, LIST_FLAG | i, __float_as_uint(q1.w));
-        else occluded = !(t < 1e-6f) && !(hit_back && shape_back_face(q0, q1, q2, d)) && (!point_light || t < light_dist);
+        else occluded = occludes_at<SITE_ROUND_LIST>(q0, q1, q2, d, t, hit_back, point_light, light_dist);
     }
     uint32_t cur = occluded ? REF_EMPTY : sc.root_ref;
     if (cur == REF_EMPTY) return occluded;
@@ -510,12 +523,13 @@ __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool a
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2];
                 float t;
                 if (COUNT) { cnt->prims++; if (first_active_lane()) { cnt->wave_prim_iters++; cnt->wave_round_prim_iters++; } }
-                if (!test_shape<SITE_CLOSEST_TREE>(q0, q1, q2, o, d, &t)) continue;
+                if (!test_shape<SITE_ROUND_TREE>(q0, q1, q2, o, d, &t)) continue;
+                MARK_AT("tested", SITE_ROUND_TREE);
                 if (!any_hit) {
                     consider(best, t, first + k, __float_as_uint(q1.w));
                     tlim = prune_limit(best->t);
                 } else {
-                    occluded = !(t < 1e-6f) && !(hit_back && shape_back_face(q0, q1, q2, d)) && (!point_light || t < light_dist);
+                    occluded = occludes_at<SITE_ROUND_TREE>(q0, q1, q2, d, t, hit_back, point_light, light_dist);
                 }
             }
             held = 0;

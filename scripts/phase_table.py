@@ -43,6 +43,10 @@ PHASE_PASSES = collections.OrderedDict([
     ("shadow_box", "shadow_box"),
     ("shadow_shape", "shadow_shape"), ("triangle_3", "shadow_shape:tree:triangle"), ("sphere_3", "shadow_shape:tree:sphere"),
     ("plane_3", "shadow_shape:tree:plane"), ("tested_3", "shadow_shape"), ("occluder_back_face_3", "never"), ("guards_3", "shadow_shape"),
+    ("round_setup", "rounds"), ("round_list", "rounds"), ("plane_4", "rounds:list:plane"), ("triangle_4", "rounds:list:triangle"),
+    ("sphere_4", "rounds:list:sphere"), ("tested_4", "rounds"), ("occluder_back_face_4", "never"), ("guards_4", "rounds"), ("round_raybox", "rounds"), ("round_box", "round_box"),
+    ("round_shape", "round_shape"), ("triangle_5", "round_shape:tree:triangle"), ("sphere_5", "round_shape:tree:sphere"),
+    ("plane_5", "round_shape:tree:plane"), ("tested_5", "round_shape"), ("occluder_back_face_5", "never"), ("guards_5", "round_shape"), ("round_collect", "rounds"),
     ("shade", "shade"), ("shade_pow", "shade"), ("shade_pow_main_path", "shade"), ("shade_pow_off_the_main_path", "never"), ("shade_sum", "shade"),
     ("level_end", "hit"), ("fold", "waves"), ("quantise", "waves"), ("epilogue", "waves"),
 ])
@@ -92,7 +96,8 @@ def passes_of(st, n_lights):
     ph = st["phase_passes"]
     waves = st["primary"] / 64.0
     return {"waves": waves, "closest": ph[0], "hit": ph[1], "light": ph[1] * n_lights, "shadow": ph[2], "shade": ph[3],
-            "closest_box": st["box_passes"] - ph[4], "shadow_box": ph[4], "closest_shape": st["shape_passes"] - ph[5], "shadow_shape": ph[5]}
+            "closest_box": st["box_passes"] - ph[4] - ph[7], "shadow_box": ph[4], "closest_shape": st["shape_passes"] - ph[5] - ph[8], "shadow_shape": ph[5],
+            "rounds": ph[6], "round_box": ph[7], "round_shape": ph[8]}
 
 
 def main():
