@@ -1,10 +1,13 @@
 // render_kernels.hip -- the per-pixel render loop as gfx950 kernels.
 //
-// One thread renders one pixel start to finish: camera ray generation, closest hit over the
+// One thread owns one pixel start to finish: camera ray generation, closest hit over the
 // always-tested list and the tree, one shadow ray per light, Lambert + Blinn-Phong shading and
 // the bounded mirror recursion of the reference, unrolled into a forward pass that records one
 // {local colour, material} per depth and a backward fold (so that the float operations happen
-// in the reference's order).  A wavefront covers an 8x8 pixel tile.
+// in the reference's order).  A wavefront covers an 8x8 pixel tile and walks the path levels
+// together; once few of its paths are left, the rays that depend on one hit only (its shadow
+// rays and the closest-hit ray of its next level) are traced side by side, one per lane, by
+// whichever lanes are free, and the pixel's own lane shades with the answers.
 //
 // Arithmetic contract.  Everything that decides a pixel is IEEE binary32 evaluated in exactly
 // the order the reference evaluates it, with no multiply-add fusion (this file is compiled
@@ -569,9 +572,6 @@ extern __shared__ uint32_t s_stack[];
 // raytracer.rs:173.  On the C library's main path (a positive normal base: every n.h that is not exactly zero) its own
 // algorithm in binary64 with the tables in LDS; +0 to a positive power is +0; whatever else comes in goes to the device library.
 __device__ __forceinline__ float specular_power(float base, float exponent, const uint64_t* tables) {
-#ifdef RT_DIAG_NO_POWF        // (timing experiments only: what the power costs at all; wrong pixels)
-    return base;
-#endif
 #ifndef RT_LIBRARY_POWF      // (for comparisons: everything through the device library)
     if (rtpow::pow_specular_domain(base, exponent)) { MARK("shade_pow_main_path"); return rtpow::pow_specular(base, exponent, tables); }
 #endif
