@@ -14,9 +14,11 @@ with one RCCL gather of the compact row buffers on GPU 0, which restores frame o
 drive them:
   --multi library (default)  rank 0 drives all N GPUs through the C ABI (rt_init_multi: RCCL inside the
                              library, what a single-process host like the reference's main gets); the
-                             other ranks only take part in the barriers.  If the library path fails
-                             while it is set up (communicators, scene broadcast, a first gathered frame), the
-                             line says so and the ranks path below is used instead.
+                             other ranks only take part in the barriers.  Rank 0 first sends a child process
+                             through that path (communicators, scene broadcast, one gathered frame, compared with the
+                             frame of one GPU); if the child fails, hangs (it is killed after 7 minutes) or gets a wrong
+                             frame, or the same set-up then fails in rank 0 itself, the line says so
+                             (`config.library_path_error`) and the ranks path below is used instead.
   --multi ranks              one process per GPU, torch.distributed ("nccl" = RCCL) for broadcast and gather.
 Frames are pipelined over the library's lanes (two deep up to four GPUs, four deep beyond): the gather of
 one frame overlaps the kernels of the next.  The total work is fixed as N grows: "scaling": "strong".
@@ -135,6 +137,95 @@ def load_counters(config):
         return {}
 
 
+def make_workload(rt, syn, config, W, H, with_scene):
+    """(frame, scene or None, what keeps the scene's arrays alive, workload name, data description) of a configuration."""
+    if config == "dragon":
+        cfg = rt.ParsedConfigState().load_config_file(SCENE)
+        cfg.set_size(W, H)
+        workload = f"final_avec_bonus.scene (dragon, 100000 triangles + plane, 2 point lights, maxdepth 5) at {W}x{H}"
+        data = ("reference scene file final_avec_bonus.scene with the size line overridden to 3840 2160" if (W, H) == (3840, 2160)
+                else f"reference scene file final_avec_bonus.scene at {W}x{H}")
+        return cfg.frame(), (cfg.scene() if with_scene else None), cfg, workload, data
+    scene_arrays = syn.product_scene(rt) if with_scene else None
+    workload = f"procedural height-field mesh, 9998592 triangles + plane, 4 point lights, maxdepth 3, at {W}x{H}"
+    return (syn.product_frame(rt, W, H), (scene_arrays.c if with_scene else None), scene_arrays, workload,
+            "synthetic mesh generated in memory (raytracer-rust_amd/synthetic.py)")
+
+
+def device_frame_to_host(ptr, H, W):
+    """A frame in device memory of the first GPU (raw pointer) copied to the host."""
+    import ctypes
+    import torch
+    host = np.empty((H, W), dtype=np.uint32)
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")      # the HIP runtime already loaded into the process (torch's copy)
+    hip = ctypes.CDLL(bundled if os.path.exists(bundled) else "libamdhip64.so")
+    assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(host.nbytes), 2) == 0      # device to host
+    return host
+
+
+def library_rehearsal(args):
+    """`--library-rehearsal`: what rank 0 runs as a child process before it commits itself to the library path on N GPUs.
+    Communicators, scene broadcast, one frame through the gather, compared with the frame of the first GPU alone; one JSON
+    object on stdout says how it went.  A hang in here costs the parent a time-out and the child its life, not the run."""
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    trouble = os.environ.get("RT_BENCH_TEST_REHEARSAL")       # for testing the parent's handling: hang | error | differ
+    try:
+        if trouble == "hang":
+            time.sleep(1e6)
+        import torch
+        rt = ge.load_package()
+        syn = importlib.import_module("raytracer_rust_amd.synthetic")
+        W, H = (args.width or (3840 if args.config == "dragon" else 7680)), (args.height or (2160 if args.config == "dragon" else 4320))
+        frame, scene, _keep, _, _ = make_workload(rt, syn, args.config, W, H, with_scene=True)
+        rt.init_multi(args.gpus)
+        if trouble == "error":
+            raise RuntimeError("asked to fail (RT_BENCH_TEST_REHEARSAL=error)")
+        rt.upload_scene(scene, gpu_build=args.config == "mesh")
+        ptr, _ = rt.render_frame(frame, want_stats=True)
+        gathered = device_frame_to_host(ptr, H, W)
+        ref = torch.zeros((H, W), dtype=torch.int32, device=torch.device("cuda", 0))
+        rt.after_torch()
+        rt.render_tiles(frame, 0, 1, ref.data_ptr(), want_stats=True)
+        alone = ref.cpu().numpy().view(np.uint32)
+        if trouble == "differ":
+            alone[H // 2, W // 2] ^= 1
+        equal = bool(np.array_equal(gathered, alone))
+        rt.shutdown()
+        report = {"ok": equal, "error": None if equal else "the frame gathered from the GPUs differs from the frame of one GPU",
+                  "frame_checksum": frame_checksum(gathered), "frame_checksum_one_gpu": frame_checksum(alone)}
+    except Exception as e:      # noqa: BLE001  (the parent reads it from the report)
+        report = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(report), file=real_stdout, flush=True)
+    return 0
+
+
+def rehearse_library_in_child(args, world, W, H):
+    """None if a child process got a correct frame through the library path on `world` GPUs, else what went wrong there."""
+    seconds = float(os.environ.get("RT_BENCH_REHEARSAL_SECONDS", "420"))
+    launcher_keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+                     "MASTER_ADDR", "MASTER_PORT")
+    env = {k: v for k, v in os.environ.items() if k not in launcher_keys and not k.startswith("TORCHELASTIC_")}
+    cmd = [sys.executable, "-u", os.path.abspath(__file__), "--library-rehearsal", "--gpus", str(world), "--config", args.config, "--width", str(W), "--height", str(H)]
+    try:
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    except OSError as e:
+        return f"rehearsal in a child process: could not start it ({e})"
+    try:
+        out, _ = child.communicate(timeout=seconds)
+    except subprocess.TimeoutExpired:
+        child.kill()                    # this child, by its process id
+        child.communicate()
+        return f"rehearsal in a child process: no answer within {seconds:.0f} s (hung; the child was killed)"
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    try:
+        report = json.loads(lines[-1])
+    except (IndexError, ValueError):
+        return f"rehearsal in a child process: exit status {child.returncode}, no report"
+    return None if report.get("ok") else f"rehearsal in a child process: {report.get('error')}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,7 +237,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="frames in flight per GPU (default: 1 on one GPU, 2 on up to four, 4 beyond)")
     ap.add_argument("--multi", choices=("library", "ranks"), default="library")
+    ap.add_argument("--library-rehearsal", action="store_true", help=argparse.SUPPRESS)      # rank 0 starts this as a child process (library_rehearsal)
     args = ap.parse_args()
+    if args.library_rehearsal:
+        return library_rehearsal(args)
     if args.config == "mesh" and args.steps == 200:
         args.steps, args.warmup = 20, 3
 
@@ -187,26 +281,10 @@ def main():
         return bool(flag.item())
 
     # ------------------------------------------------------------------ the workload
-    cfg = scene = None
     W, H = (args.width or (3840 if args.config == "dragon" else 7680)), (args.height or (2160 if args.config == "dragon" else 4320))
     mode, library_error = ("single" if world == 1 and not rehearse else args.multi), None
     gpu_build = args.config == "mesh"
-    frame = None
-    if args.config == "dragon":
-        cfg = rt.ParsedConfigState().load_config_file(SCENE)
-        cfg.set_size(W, H)
-        frame = cfg.frame()
-        scene = cfg.scene() if rank == 0 else None
-        workload = f"final_avec_bonus.scene (dragon, 100000 triangles + plane, 2 point lights, maxdepth 5) at {W}x{H}"
-        data = ("reference scene file final_avec_bonus.scene with the size line overridden to 3840 2160" if (W, H) == (3840, 2160)
-                else f"reference scene file final_avec_bonus.scene at {W}x{H}")
-    else:
-        if rank == 0:
-            scene_arrays = syn.product_scene(rt)
-            scene = scene_arrays.c
-        frame = syn.product_frame(rt, W, H)
-        workload = f"procedural height-field mesh, 9998592 triangles + plane, 4 point lights, maxdepth 3, at {W}x{H}"
-        data = "synthetic mesh generated in memory (raytracer-rust_amd/synthetic.py)"
+    frame, scene, _keep, workload, data = make_workload(rt, syn, args.config, W, H, with_scene=rank == 0)
 
     # ------------------------------------------------------------------ how the GPUs are driven
     # Library path: rank 0 sets up everything that can fail or hang inside RCCL (communicators, the broadcast of the scene,
@@ -218,6 +296,10 @@ def main():
     if mode == "library":
         ok = True
         if rank == 0:
+            # First in a child process, which a hang costs nothing but a time-out; only then in this one.
+            library_error = rehearse_library_in_child(args, world, W, H)
+            ok = library_error is None
+        if rank == 0 and ok:
             try:
                 watchdog.arm(180, f"rt_init_multi({world}) (ncclCommInitAll over {world} GPUs)")
                 rt.init_multi(world)
@@ -281,15 +363,6 @@ def main():
         if dist.is_initialized():
             dist.barrier()
 
-    def to_host(ptr):
-        """A frame in device memory of the first GPU (raw pointer) copied to the host."""
-        import ctypes
-        host = np.empty((H, W), dtype=np.uint32)
-        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")      # the HIP runtime already loaded into the process (torch's copy)
-        hip = ctypes.CDLL(bundled if os.path.exists(bundled) else "libamdhip64.so")
-        assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(host.nbytes), 2) == 0      # device to host
-        return host
-
     # ------------------------------------------------------------------ the frame of N GPUs must be the frame of one
     # Before anything is timed: the same frame rendered by the first GPU alone (one shard of one) and through the path
     # the timed loop uses; they must agree in every pixel, and the line carries both checksums.
@@ -313,7 +386,7 @@ def main():
                 multi_equal = bool(np.array_equal(out.cpu().numpy().view(np.uint32), alone))
         elif rank == 0:
             ptr, _ = rt.render_frame(frame, want_stats=True)
-            multi_equal = bool(np.array_equal(to_host(ptr), alone))
+            multi_equal = bool(np.array_equal(device_frame_to_host(ptr, H, W), alone))
         watchdog.disarm()
 
     # ------------------------------------------------------------------ timed region
@@ -369,7 +442,7 @@ def main():
         if mode == "ranks":
             frame_host = out.cpu().numpy().view(np.uint32)
         else:
-            frame_host = to_host(out)
+            frame_host = device_frame_to_host(out, H, W)
         checksum = frame_checksum(frame_host)
         if multi_equal is not None:
             multi_equal = multi_equal and checksum == one_gpu_checksum       # the last timed frame too
