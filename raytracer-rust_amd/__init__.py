@@ -97,6 +97,7 @@ _SIGNATURES = {
     "rt_tile_costs_count": (C.c_int, [C.POINTER(rt_frame), C.c_int, C.POINTER(C.c_uint32)]),
     "rt_tile_costs_export": (C.c_int, [C.POINTER(rt_frame), C.c_int, C.c_void_p, C.c_uint32]),
     "rt_tile_costs_import": (C.c_int, [C.POINTER(rt_frame), C.c_int, C.c_void_p, C.c_uint32]),
+    "rt_tile_costs_guess": (C.c_int, [C.POINTER(rt_frame), C.c_int, C.c_void_p, C.c_uint32]),
     "rt_select_lane": (C.c_int, [C.c_int]),
     "rt_stream": (C.c_void_p, []),
     "rt_synchronize": (C.c_int, []),
@@ -617,6 +618,14 @@ def tile_costs_export(frame, gpu=0):
     """Costs measured by the last launch of `frame` on the current lane (uint32 per region)."""
     costs = np.zeros(tile_costs_count(frame, gpu), dtype=np.uint32)
     _check(lib().rt_tile_costs_export(C.byref(frame), int(gpu), costs.ctypes.data, len(costs)))
+    return costs
+
+
+def tile_costs_guess(frame, gpu=0):
+    """What the first launch of `frame` since the upload is ordered by: shapes of the tree seen in and around every region,
+    directly and in the specular planes (uint32 per region)."""
+    costs = np.zeros(tile_costs_count(frame, gpu), dtype=np.uint32)
+    _check(lib().rt_tile_costs_guess(C.byref(frame), int(gpu), costs.ctypes.data, len(costs)))
     return costs
 
 

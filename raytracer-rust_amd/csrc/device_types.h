@@ -81,6 +81,10 @@ inline RenderPlan rtk_render_plan(int stack_depth, uint32_t maxdepth) {
 // and d_cost is left zeroed.
 extern "C" hipError_t rtk_launch_sort_regions(uint32_t* d_cost, uint32_t n, uint32_t* d_order, uint32_t* d_last, hipStream_t stream);
 
+// Writes a guess at every region's cost to d_cost (n_regions words) from where the tree's shapes are on screen; for the
+// first launch of a frame geometry.  f: as for the launch, region fields filled in.  d_seen: n_regions words of scratch.
+extern "C" hipError_t rtk_launch_predict_regions(const DevScene* sc, const DevFrame* f, uint32_t n_tree_shapes, uint32_t* d_seen, uint32_t* d_cost, hipStream_t stream);
+
 extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, uint32_t* d_out, float4* d_fold,
                                         unsigned long long* d_counters, int stack_depth, RenderPlan plan, int count, hipStream_t stream);
 extern "C" hipError_t rtk_launch_assemble(const uint32_t* d_gathered, uint32_t stride_rows, uint32_t nshards, uint32_t tile_rows,

@@ -108,6 +108,7 @@ extern "C" {
     pub fn rt_tile_costs_count(frame: *const rt_frame, gpu: c_int, count: *mut u32) -> c_int;
     pub fn rt_tile_costs_export(frame: *const rt_frame, gpu: c_int, costs: *mut u32, count: u32) -> c_int;
     pub fn rt_tile_costs_import(frame: *const rt_frame, gpu: c_int, costs: *const u32, count: u32) -> c_int;
+    pub fn rt_tile_costs_guess(frame: *const rt_frame, gpu: c_int, costs: *mut u32, count: u32) -> c_int;
     /// `RT_LANES` = 4 lanes (stream + work buffers each); launches on different lanes may overlap on the GPU.
     pub fn rt_select_lane(lane: c_int) -> c_int;
     pub fn rt_stream() -> *mut c_void;

@@ -259,6 +259,67 @@ def test_two_tracers_each_render_their_own_scene():
         rt.init(0)
 
 
+def test_first_frame_is_ordered_by_where_the_shapes_are_on_screen():
+    """The first launch after an upload has no measured costs; its regions go by a guess: twice the tree shapes seen in a
+    region plus their mirror images in the specular planes, summed over the five by five regions around it.  Checked
+    against the same count in numpy (projection as raytracer.rs:61-66 inverted), for a whole frame and for one of three
+    shards; and the order changes no pixel."""
+    import struct
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
+    cfg.set_size(1920, 1080)                                  # 240 x 135 tiles: regions of 8 x 8 tiles, 30 x 17 of them
+    scene, frame = cfg.scene(), cfg.frame()
+    blob, _ = rt.pack_scene_host(scene)
+    hdr = struct.unpack_from("<IIQ5Q5I", blob, 0)
+    shapes = np.frombuffer(blob, dtype=np.float32, count=hdr[9] * 12, offset=hdr[4]).reshape(-1, 12)
+    plane = np.frombuffer(blob, dtype=np.float32, count=12, offset=hdr[5])      # the floor: the one always-tested shape, specular
+    assert hdr[10] == 1 and (plane[3:4].view(np.uint32)[0] & 3) == 2
+    pos, cv, right, up = (np.array(v[:], dtype=np.float64) for v in (frame.pos, frame.cv, frame.right, frame.up))
+
+    def guess(nshards):
+        rows = rt.shard_rows(frame.height, 0, nshards)
+        nx, ny = -(-frame.width // 64), -(-rows // 64)
+        seen = np.zeros((ny, nx))
+        v = shapes[:, 0:3].astype(np.float64)
+        p0, n = plane[0:3].astype(np.float64), plane[8:11].astype(np.float64)
+        for pts, weight in ((v, 2), (v - 2 * ((v - p0) @ n)[:, None] * n[None, :], 1)):
+            q = pts - pos
+            depth = q @ cv
+            px = (q @ right) / depth / frame.pixel_w * frame.half_w + frame.half_w
+            py = frame.half_h - (q @ up) / depth / frame.pixel_h * frame.half_h
+            ok = (depth > 0) & (px >= 0) & (px < frame.width) & (py >= 0) & (py < frame.height)
+            y = py[ok].astype(np.int64)
+            local = (y // 8 // nshards) * 8 + y % 8
+            keep = local // 64 < ny
+            np.add.at(seen, ((local // 64)[keep], (px[ok].astype(np.int64) // 64)[keep]), weight)
+        padded = np.pad(seen, 2)
+        return sum(padded[a:a + ny, b:b + nx] for a in range(5) for b in range(5)).ravel()
+
+    rt.upload_scene(scene)
+    got, want = rt.tile_costs_guess(frame).astype(np.float64), guess(1)
+    assert got.shape == want.shape == (510,)
+    # binary32 on the device against binary64 here: a shape on a region's border may fall on either side
+    assert abs(got.sum() - want.sum()) <= 1e-3 * want.sum() and np.abs(got - want).max() <= 0.01 * want.max(), (got.sum(), want.sum(), np.abs(got - want).max())
+    order_got, order_want = np.argsort(-got, kind="stable"), np.argsort(-want, kind="stable")
+    assert len(set(order_got[:100]) & set(order_want[:100])) >= 95
+    with pytest.raises(rt.RtError, match="has not been rendered"):           # asking for the guess starts nothing
+        rt.tile_costs_export(frame)
+    first = rt.render(frame)[0].copy()                        # ordered by the guess
+    measured = rt.tile_costs_export(frame)
+    assert np.corrcoef(got, measured.astype(np.float64))[0, 1] > 0.5, "the guess says little about the measured costs"
+    again = rt.render(frame)[0]                               # ordered by the measured costs
+    assert np.array_equal(first, again)
+    # one of three shards, as a process per GPU renders it: the guess is made for the rows that shard owns
+    torch = pytest.importorskip("torch")
+    rows = rt.shard_rows(frame.height, 0, 3)
+    buf = torch.zeros((rows, frame.width), dtype=torch.int32, device="cuda")
+    hold = rt.after_torch()
+    rt.upload_scene(scene)
+    rt.render_tiles(frame, 0, 3, buf.data_ptr())
+    rt.synchronize()
+    del hold
+    assert np.array_equal(buf.cpu().numpy().view(np.uint32), np.concatenate([first[t * 8:(t + 1) * 8] for t in range(0, 135, 3)]))
+
+
 def test_tile_costs_carry_over_to_a_new_upload_and_change_no_pixel(tmp_path):
     """The measured costs of the tile regions can be taken out after a frame and handed back after the scene has been
     uploaded again (a later run of the same scene file): they set the order of the work of the first launch, nothing
