@@ -18,6 +18,7 @@ struct SceneParts {
     const rtl::MaterialRec* mats; uint32_t n_mats;
     const rtl::LightRec* lights; uint32_t n_lights;
     uint32_t finite_shading;
+    uint32_t tree_kinds;       // bit k set: `tree` holds shapes of kind k (goes into the blob header)
     float pad_abs;             // absolute outward padding of every node box (the host builder's rule)
     uint32_t depth_limit;      // deepest tree the render kernels can traverse
 };

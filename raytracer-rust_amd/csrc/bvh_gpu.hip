@@ -850,7 +850,7 @@ BuildStatus build_scene_on_gpu(const SceneParts& in, hipStream_t stream, BuiltSc
     h.magic = rtl::BLOB_MAGIC; h.version = rtl::BLOB_VERSION;
     h.n_pairs = n_pairs; h.n_tree_shapes = n; h.n_list_shapes = in.n_list; h.n_materials = in.n_mats; h.n_lights = in.n_lights;
     h.root_ref = rtl::inner_ref(root_ref);
-    h.max_depth = stats.max_depth; h.finite_shading = in.finite_shading;
+    h.max_depth = stats.max_depth; h.finite_shading = in.finite_shading; h.tree_kinds = in.tree_kinds;
     h.n_leaves = stats.n_leaves; h.max_leaf = stats.max_leaf;
     h.sah_cost = (float)((double)stats.cost_micro * 1e-6);
     size_t off = sizeof(rtl::BlobHeader);

@@ -14,6 +14,7 @@ struct DevScene {
     const float4* lights;   // 2 float4 per light
     uint32_t n_list, n_lights, root_ref;
     uint32_t finite_shading;   // 1 when every material and light value is finite (lets zero contributions be skipped)
+    uint32_t tree_kinds;       // bit k set: the tree holds shapes of kind k (layout.h); only triangles selects the kernel built for that
     float grid_origin[3], grid_scale[3];   // node box coordinate q on axis k = grid_origin[k] + q * grid_scale[k]
     float inv_limit[3];                    // bound on |1 / direction| per axis that keeps grid_scale / direction and its multiples finite
 };

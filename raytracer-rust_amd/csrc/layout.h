@@ -44,7 +44,7 @@ constexpr uint32_t KIND_SPHERE = 0, KIND_TRIANGLE = 1, KIND_PLANE = 2;
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_EMPTY = 0xFFFFFFFFu;   // never produced for a real leaf (would need first = 2^28 - 1)
 constexpr uint32_t MAX_LEAF = 8;
-constexpr uint32_t MAX_TREE_SHAPES = 1u << 26;   // fewer node pairs than 2^26: their byte offsets leave bit 31 of a reference free
+constexpr uint32_t MAX_TREE_SHAPES = 1u << 26;   // fewer node pairs than 2^26: their byte offsets leave bit 31 of a reference free; and the byte offset of a shape (48 x its index) fits 32 bits
 
 inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) { return REF_LEAF | (first << 3) | (count - 1); }
 // A builder's reference (pair index or leaf) -> the blob's.
@@ -82,7 +82,7 @@ struct MaterialRec { float diffuse[3]; float shininess; float specular[3]; float
 struct LightRec { float v[3]; float kind; float color[3]; float pad; };
 
 constexpr uint32_t BLOB_MAGIC = 0x52544231u;   // "RTB1"
-constexpr uint32_t BLOB_VERSION = 6;
+constexpr uint32_t BLOB_VERSION = 7;
 
 struct BlobHeader {
     uint32_t magic, version;
@@ -94,7 +94,8 @@ struct BlobHeader {
     float sah_cost;
     uint32_t finite_shading;   // 1 when every material and light value is finite
     float grid_origin[3], grid_scale[3];   // node box coordinate q on axis k = grid_origin[k] + q * grid_scale[k]
-    uint32_t pad[64 - 31];
+    uint32_t tree_kinds;       // bit k set: the tree holds shapes of kind k (a tree of triangles only gets the kernel built for that)
+    uint32_t pad[64 - 32];
 };
 static_assert(sizeof(BlobHeader) == 256, "blob header must be 256 bytes");
 

@@ -123,6 +123,24 @@ __device__ __forceinline__ bool test_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, f
     return true;
 }
 
+// The same test as straight-line code: every quantity is computed, the four rejections are combined at the end.  Each condition
+// sees the value the reference would have computed had it got that far, and the reference rejects as soon as one of them
+// holds, so the outcome (and t for an accepted hit) is the same; what a rejected candidate leaves in *t_out is not used.
+// In a wavefront that tests a leaf per lane some lane nearly always reaches the end, so leaving early saves little, while
+// the exec-mask bookkeeping of four nested exits costs more scalar instructions than the test has vector ones.
+__device__ __forceinline__ bool test_triangle_straight(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float* t_out) {   // shape.rs:151-176
+    const V3 h = vcross(d, e2);
+    const float a = vdot(e1, h);
+    const float f = 1.0f / a;
+    const V3 s = vsub(o, v0);
+    const float u = f * vdot(s, h);
+    const V3 q = vcross(s, e1);
+    const float v = f * vdot(d, q);
+    const float t = f * vdot(e2, q);
+    *t_out = t;
+    return !(fabsf(a) < 1e-6f) & !(u < 0.0f || u > 1.0f) & !(v < 0.0f || u + v > 1.0f) & !(t < 0.0f);
+}
+
 __device__ __forceinline__ bool test_sphere(V3 c, float radius, V3 o, V3 d, float* t_out) {      // shape.rs:72-83
     V3 oc = vsub(o, c);
     float half_b = vdot(oc, d);
@@ -144,8 +162,10 @@ __device__ __forceinline__ bool test_plane(V3 p, V3 n, V3 o, V3 d, float* t_out)
     return true;
 }
 
-template <int SITE>
+// TRI: the caller knows the shape to be a triangle (a tree that holds nothing else): no dispatch, straight-line test.
+template <int SITE, bool TRI = false>
 __device__ __forceinline__ bool test_shape(const float4 q0, const float4 q1, const float4 q2, V3 o, V3 d, float* t_out) {
+    if (TRI) { MARK_AT("triangle", SITE); return test_triangle_straight(v3(q0), v3(q1), v3(q2), o, d, t_out); }
     uint32_t kind = __float_as_uint(q0.w) & 3u;
     if (kind == KIND_TRIANGLE) { MARK_AT("triangle", SITE); return test_triangle(v3(q0), v3(q1), v3(q2), o, d, t_out); }
     if (kind == KIND_SPHERE) { MARK_AT("sphere", SITE); return test_sphere(v3(q0), q1.x, o, d, t_out); }
@@ -246,7 +266,7 @@ __device__ __forceinline__ void consider(Best* b, float t, uint32_t prim, uint32
     if (take) { b->t = t; b->prim = prim; b->order = order; }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool TRI>
 __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint32_t* stack, Best* best, Counters* cnt) {
     best->t = INF; best->prim = NO_PRIM; best->order = 0xFFFFFFFFu;
     MARK("closest_list");
@@ -287,7 +307,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             const uint32_t r0 = c0.w, r1 = c1.w;
             const bool both = h0 && h1, any = h0 || h1, swap = t1 < t0;
             const uint32_t far_child = swap ? r0 : r1;
-            if (both) low[128] = far_child;
+            low[128] = far_child;                               // a push when both are hit; otherwise a store to the free entry above the top, cheaper than a branch around it
             // where the step leads, and what a pop would return from there
             const uint32_t next = both ? (swap ? r1 : r0) : (any ? (h0 ? r0 : r1) : below);
             const uint32_t under = both ? far_child : (any ? below : below2);
@@ -309,17 +329,15 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
             uint32_t below = low[64];
             asm volatile("" : "+v"(below));                     // read under the shape loads
             for (uint32_t k = 0; k < count; k++) {
-                const float4* p = sc.tree + 3 * (size_t)(first + k);
+                const float4* p = (const float4*)((const char*)sc.tree + (first + k) * 48u);      // fewer than 2^26 shapes: the byte offset fits 32 bits and the address one register
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2];
                 float t;
                 if (COUNT) { cnt->prims++; if (first_active_lane()) cnt->wave_prim_iters++; }
-                const bool hit = test_shape<SITE_CLOSEST_TREE>(q0, q1, q2, o, d, &t);
+                const bool hit = test_shape<SITE_CLOSEST_TREE, TRI>(q0, q1, q2, o, d, &t);
                 MARK_AT("tested", SITE_CLOSEST_TREE);
-                if (hit) {
-                    consider(best, t, first + k, __float_as_uint(q1.w));
-                    tlim = prune_limit(best->t);
-                }
+                if (hit) consider(best, t, first + k, __float_as_uint(q1.w));
             }
+            tlim = prune_limit(best->t);                        // (infinite while nothing has been hit)
             held = 0;
             if ((cur & REF_LEAF) && cur != REF_EMPTY) {
                 held = cur;
@@ -328,6 +346,21 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
         }
         if (cur == REF_EMPTY) break;
     }
+}
+
+// The guards of raytracer.rs:143-159 for a candidate whose exact test gave `hit` and distance t.  Most candidates of a shadow
+// ray are missed by every lane, so the guards sit behind a branch (measured against selects: 1 % in their favour); the
+// other one is around the occluder's own facing, which is needed for back-face hits only.
+template <int SITE>
+__device__ __forceinline__ bool occludes_at(bool hit, const float4 q0, const float4 q1, const float4 q2, V3 d, float t, bool hit_back, bool point_light, float light_dist) {
+    if (!hit) return false;
+    bool blocks = !(t < 1e-6f) & (!point_light | (t < light_dist));
+    if (blocks && hit_back) {
+        MARK_AT("occluder_back_face", SITE);
+        blocks = !shape_back_face(q0, q1, q2, d);
+    }
+    MARK_AT("guards", SITE);
+    return blocks;
 }
 
 // raytracer.rs:143-159 for one candidate.
@@ -348,7 +381,7 @@ __device__ __forceinline__ bool occludes(const float4 q0, const float4 q1, const
     return true;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool TRI>
 __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool hit_back, bool point_light, float light_dist, uint32_t* stack,
                                           Counters* cnt) {
     MARK("shadow_list");
@@ -380,7 +413,7 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
             if (COUNT) { cnt->nodes += 2; if (first_active_lane()) { cnt->wave_node_iters++; cnt->wave_shadow_node_iters++; } }
             const uint32_t r0 = c0.w, r1 = c1.w;
             const bool both = h0 && h1, any = h0 || h1;
-            if (both) low[128] = r1;
+            low[128] = r1;                                      // as in closest_hit: a push, or a store to the free entry above the top
             const uint32_t next = h0 ? r0 : (h1 ? r1 : below);
             const uint32_t under = both ? r1 : (any ? below : below2);
             const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
@@ -399,9 +432,13 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
             uint32_t below = low[64];
             asm volatile("" : "+v"(below));                     // read under the shape loads
             for (uint32_t k = 0; k < count; k++) {
-                const float4* p = sc.tree + 3 * (size_t)(first + k);
+                const float4* p = (const float4*)((const char*)sc.tree + (first + k) * 48u);      // fewer than 2^26 shapes: the byte offset fits 32 bits and the address one register
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                float t;
                 if (COUNT) { cnt->prims++; if (first_active_lane()) { cnt->wave_prim_iters++; cnt->wave_shadow_prim_iters++; } }
-                if (occludes<SITE_SHADOW_TREE>(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
+                const bool hit = test_shape<SITE_SHADOW_TREE, TRI>(q0, q1, q2, o, d, &t);
+                MARK_AT("tested", SITE_SHADOW_TREE);
+                if (occludes_at<SITE_SHADOW_TREE>(hit, q0, q1, q2, d, t, hit_back, point_light, light_dist)) return true;
             }
             held = 0;
             if ((cur & REF_LEAF) && cur != REF_EMPTY) {
@@ -436,7 +473,7 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
             uint32_t below = low[64];
             asm volatile("" : "+v"(below));       // read under the shape loads
             for (uint32_t k = 0; k < count; k++) {
-                const float4* p = sc.tree + 3 * (size_t)(first + k);
+                const float4* p = (const float4*)((const char*)sc.tree + (first + k) * 48u);      // fewer than 2^26 shapes: the byte offset fits 32 bits and the address one register
                 if (COUNT) { cnt->prims++; if (first_active_lane()) { cnt->wave_prim_iters++; cnt->wave_shadow_prim_iters++; } }
                 if (occludes<SITE_SHADOW_TREE>(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
             }
@@ -452,22 +489,10 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
 #ifndef RT_SIDE_ROUNDS_MAX
 #define RT_SIDE_ROUNDS_MAX 2u
 #endif
-// The guards of raytracer.rs:143-159 for a candidate that the exact test accepts at distance t.
-template <int SITE>
-__device__ __forceinline__ bool occludes_at(const float4 q0, const float4 q1, const float4 q2, V3 d, float t, bool hit_back, bool point_light, float light_dist) {
-    bool blocks = !(t < 1e-6f) && (!point_light || t < light_dist);
-    if (blocks && hit_back) {
-        MARK_AT("occluder_back_face", SITE);
-        blocks = !shape_back_face(q0, q1, q2, d);
-    }
-    MARK_AT("guards", SITE);
-    return blocks;
-}
-
 // One ray of either kind through the loop of closest_hit: a closest-hit ray as there, a shadow ray (any_hit) with the guards of
 // raytracer.rs:143-159 and an end at the first occluder.  For rounds in which the lanes of a wavefront carry rays of both kinds.
 // Result: *best for a closest-hit ray; the return value says whether a shadow ray found an occluder.
-template <bool COUNT>
+template <bool COUNT, bool TRI>
 __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool any_hit, bool hit_back, bool point_light, float light_dist,
                                           uint32_t* stack, Best* best, Counters* cnt) {
     best->t = INF; best->prim = NO_PRIM; best->order = 0xFFFFFFFFu;
@@ -480,7 +505,7 @@ __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool a
         if (!test_shape<SITE_ROUND_LIST>(q0, q1, q2, o, d, &t)) continue;
         MARK_AT("tested", SITE_ROUND_LIST);
         if (!any_hit) consider(best, t, LIST_FLAG | i, __float_as_uint(q1.w));
-        else occluded = occludes_at<SITE_ROUND_LIST>(q0, q1, q2, d, t, hit_back, point_light, light_dist);
+        else occluded = occludes_at<SITE_ROUND_LIST>(true, q0, q1, q2, d, t, hit_back, point_light, light_dist);
     }
     uint32_t cur = occluded ? REF_EMPTY : sc.root_ref;
     if (cur == REF_EMPTY) return occluded;
@@ -503,7 +528,7 @@ __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool a
             const uint32_t r0 = c0.w, r1 = c1.w;
             const bool both = h0 && h1, any = h0 || h1, swap = t1 < t0;
             const uint32_t far_child = swap ? r0 : r1;
-            if (both) low[128] = far_child;
+            low[128] = far_child;
             const uint32_t next = both ? (swap ? r1 : r0) : (any ? (h0 ? r0 : r1) : below);
             const uint32_t under = both ? far_child : (any ? below : below2);
             const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
@@ -522,19 +547,17 @@ __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool a
             uint32_t below = low[64];
             asm volatile("" : "+v"(below));
             for (uint32_t k = 0; k < count && !occluded; k++) {
-                const float4* p = sc.tree + 3 * (size_t)(first + k);
+                const float4* p = (const float4*)((const char*)sc.tree + (first + k) * 48u);      // fewer than 2^26 shapes: the byte offset fits 32 bits and the address one register
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2];
                 float t;
                 if (COUNT) { cnt->prims++; if (first_active_lane()) { cnt->wave_prim_iters++; cnt->wave_round_prim_iters++; } }
-                if (!test_shape<SITE_ROUND_TREE>(q0, q1, q2, o, d, &t)) continue;
+                const bool hit = test_shape<SITE_ROUND_TREE, TRI>(q0, q1, q2, o, d, &t);
                 MARK_AT("tested", SITE_ROUND_TREE);
-                if (!any_hit) {
-                    consider(best, t, first + k, __float_as_uint(q1.w));
-                    tlim = prune_limit(best->t);
-                } else {
-                    occluded = occludes_at<SITE_ROUND_TREE>(q0, q1, q2, d, t, hit_back, point_light, light_dist);
-                }
+                if (!hit) continue;
+                if (!any_hit) consider(best, t, first + k, __float_as_uint(q1.w));
+                else occluded = occludes_at<SITE_ROUND_TREE>(true, q0, q1, q2, d, t, hit_back, point_light, light_dist);
             }
+            tlim = any_hit ? tlim : prune_limit(best->t);
             held = 0;
             if (occluded) { cur = REF_EMPTY; break; }
             if ((cur & REF_LEAF) && cur != REF_EMPTY) {
@@ -582,7 +605,8 @@ __device__ __forceinline__ float specular_power(float base, float exponent, cons
 
 // FOLD_LDS: the {local colour, material} records of the reflection levels live in LDS behind the stacks
 // ([level][lane], 16 bytes each), those of the deeper levels in the global `fold` array ([level - lds_levels][pixel]).
-template <bool COUNT>
+// TRI: the tree holds nothing but triangles (the builders say so in the blob header).
+template <bool COUNT, bool TRI>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT_WAVES))) void render_kernel(DevScene sc, DevFrame f, uint32_t* __restrict__ out,
                                                                                                         float4* __restrict__ fold, unsigned long long* __restrict__ counters,
                                                                                                         uint32_t stack_entries, uint32_t lds_levels) {
@@ -642,7 +666,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
             Best best = next;
             if (alive && !have_next) {
                 if (COUNT && first_active_lane()) cnt.wave_closest++;
-                closest_hit<COUNT>(sc, o, d, stack, &best, &cnt);
+                closest_hit<COUNT, TRI>(sc, o, d, stack, &best, &cnt);
             }
             MARK("hit");
             if (alive && best.prim == NO_PRIM) { cur = v3(0.0f, 0.0f, 0.0f); alive = false; }   // raytracer.rs:199-201
@@ -722,7 +746,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
                     Best found = {0.0f, NO_PRIM, 0u};
                     bool occluded = false;
                     if (need) {
-                        occluded = trace_job<COUNT>(sc, vadd(at, vscale(nrm, 1e-6f)), ray_dir, shadow_job, (flags & 1u) != 0u, point_light, light_dist, stack, &found, &cnt);
+                        occluded = trace_job<COUNT, TRI>(sc, vadd(at, vscale(nrm, 1e-6f)), ray_dir, shadow_job, (flags & 1u) != 0u, point_light, light_dist, stack, &found, &cnt);
                     }
                     MARK("round_collect");
                     const uint32_t word = shadow_job ? ((need && !occluded) ? 1u : 0u) : found.prim;
@@ -762,7 +786,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
                         if (!((lit >> li) & 1u)) continue;
                     } else {
                         if (COUNT && first_active_lane()) cnt.wave_shadow++;
-                        if (in_shadow<COUNT>(sc, shadow_origin, light_dir, back, point_light, light_dist, stack, &cnt)) continue;
+                        if (in_shadow<COUNT, TRI>(sc, shadow_origin, light_dir, back, point_light, light_dist, stack, &cnt)) continue;
                     }
                     MARK("shade");
                     if (COUNT && first_active_lane()) cnt.wave_shade++;
@@ -940,8 +964,9 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
 #ifdef RT_DIAG_LDS_PAD
     { static const char* pad = getenv("RT_DIAG_LDS_PAD"); if (pad) lds_bytes = std::max(lds_bytes, (size_t)atoi(pad)); }   // occupancy experiments (scripts/ab_occ.sh)
 #endif
-    if (count) hipLaunchKernelGGL(render_kernel<true>, grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries, plan.lds_levels);
-    else hipLaunchKernelGGL(render_kernel<false>, grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries, plan.lds_levels);
+    const bool tri = sc->tree_kinds == (1u << KIND_TRIANGLE);
+    auto kernel = count ? (tri ? render_kernel<true, true> : render_kernel<true, false>) : (tri ? render_kernel<false, true> : render_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, *sc, *f, d_out, d_fold, d_counters, entries, plan.lds_levels);
     return hipGetLastError();
 }
 

@@ -145,7 +145,7 @@ void point_at_blob(Device& dev, const rtl::BlobHeader& h) {
     dev.dsc.list = (const float4*)(base + h.off_list_shapes);
     dev.dsc.mats = (const float4*)(base + h.off_materials);
     dev.dsc.lights = (const float4*)(base + h.off_lights);
-    dev.dsc.n_list = h.n_list_shapes; dev.dsc.n_lights = h.n_lights; dev.dsc.root_ref = h.root_ref; dev.dsc.finite_shading = h.finite_shading;
+    dev.dsc.n_list = h.n_list_shapes; dev.dsc.n_lights = h.n_lights; dev.dsc.root_ref = h.root_ref; dev.dsc.finite_shading = h.finite_shading; dev.dsc.tree_kinds = h.tree_kinds;
     for (int k = 0; k < 3; k++) {
         dev.dsc.grid_origin[k] = h.grid_origin[k]; dev.dsc.grid_scale[k] = h.grid_scale[k];
         dev.dsc.inv_limit[k] = std::fmin(1e30f, 1e32f / std::fmax(h.grid_scale[k], 1e-30f));     // 131072 * scale / d stays finite
@@ -507,7 +507,7 @@ int rt_upload_scene_ex(const rt_scene* scene, uint32_t flags) {
     in.list = parts.list.data(); in.n_list = (uint32_t)parts.list.size();
     in.mats = parts.mats.data(); in.n_mats = (uint32_t)parts.mats.size();
     in.lights = parts.lights.data(); in.n_lights = (uint32_t)parts.lights.size();
-    in.finite_shading = parts.finite_shading; in.pad_abs = parts.pad_abs; in.depth_limit = rtp::TREE_DEPTH_LIMIT;
+    in.finite_shading = parts.finite_shading; in.tree_kinds = parts.tree_kinds; in.pad_abs = parts.pad_abs; in.depth_limit = rtp::TREE_DEPTH_LIMIT;
     if (sync_lanes()) return 1;
     rtg::BuiltScene built{};
     rtg::BuildStatus st = rtg::build_scene_on_gpu(in, cur().stream, &built, &err);

@@ -53,6 +53,13 @@ void fill_record(const rt_scene& s, const Flat& f, rtl::ShapeRec* r) {
 
 }  // namespace
 
+uint32_t kinds_of(const rtl::ShapeRec* records, size_t n) {
+    uint32_t kinds = 0;
+#pragma omp parallel for schedule(static) reduction(| : kinds) if (n > 100000)
+    for (int64_t i = 0; i < (int64_t)n; i++) kinds |= 1u << (records[i].kind_mat & 3u);
+    return kinds;
+}
+
 bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err) {
     if (h.magic != rtl::BLOB_MAGIC || h.version != rtl::BLOB_VERSION) { *err = "scene blob: bad magic or version"; return false; }
     if (h.total_bytes != bytes) { *err = "scene blob: size does not match its header"; return false; }
@@ -65,6 +72,7 @@ bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err) {
         return false;
     }
     if (h.n_pairs >= (1u << 26)) { *err = "scene blob: too many node pairs for 31-bit offsets"; return false; }
+    if (h.n_tree_shapes > rtl::MAX_TREE_SHAPES) { *err = "scene blob: too many tree shapes for 32-bit offsets"; return false; }
     if (h.max_depth > TREE_DEPTH_LIMIT) { *err = "scene blob: tree deeper than the traversal stack"; return false; }
     if (h.root_ref != rtl::REF_EMPTY) {
         if (h.root_ref & rtl::REF_LEAF) {
@@ -96,6 +104,8 @@ bool validate_blob(const uint8_t* blob, size_t bytes, std::string* err) {
         *err = "scene blob: shape with an unknown kind or material";
         return false;
     }
+    // (the header's word chooses the kernel: a tree said to hold only triangles is tested as triangles)
+    if (h.tree_kinds != kinds_of((const rtl::ShapeRec*)(blob + h.off_tree_shapes), h.n_tree_shapes)) { *err = "scene blob: kinds of the tree's shapes differ from the header"; return false; }
     if (h.root_ref == rtl::REF_EMPTY || (h.root_ref & rtl::REF_LEAF)) {
         if (h.n_pairs != 0) { *err = "scene blob: node pairs without a root"; return false; }
         return true;
@@ -259,6 +269,7 @@ bool split_scene(const rt_scene& s, SceneParts* out, std::string* err) {
         for (int k = 1; k < 7; k++) finite = finite && std::isfinite(l[k]);
     }
     out->finite_shading = finite ? 1u : 0u;
+    out->tree_kinds = kinds_of(out->tree.data(), out->tree.size());
     return true;
 }
 
@@ -304,7 +315,7 @@ bool pack_scene(const rt_scene& s, rtu::NoInitVector<uint8_t>* blob, rt_bvh_info
     h.off_materials = off; off = align256(off + mats.size() * sizeof(rtl::MaterialRec));
     h.off_lights = off; off = align256(off + (size_t)s.nlights * sizeof(rtl::LightRec));
     h.total_bytes = off;
-    h.finite_shading = parts.finite_shading;
+    h.finite_shading = parts.finite_shading; h.tree_kinds = parts.tree_kinds;
     blob->resize(off);
     {   // every section is written in full below; only the gaps up to the next 256-byte boundary need zeros
         const size_t ends[5] = {h.off_nodes + (size_t)h.n_pairs * sizeof(rtl::QuantPair), h.off_tree_shapes + nt * sizeof(rtl::ShapeRec),

@@ -39,10 +39,13 @@ struct SceneParts {
     std::vector<rtl::MaterialRec> mats;
     std::vector<rtl::LightRec> lights;
     uint32_t finite_shading = 1;
+    uint32_t tree_kinds = 0;      // bit k set: `tree` holds shapes of kind k
     float pad_abs = 0.0f;
     bool use_tree = false;
 };
 bool split_scene(const rt_scene& s, SceneParts* out, std::string* err);
+// Which kinds of shape the n records hold, one bit per kind (layout.h).
+uint32_t kinds_of(const rtl::ShapeRec* records, size_t n);
 
 // Checks a blob header copied back from the device before the kernels are pointed at it.
 bool validate_header(const rtl::BlobHeader& h, size_t bytes, std::string* err);

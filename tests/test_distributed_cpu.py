@@ -47,7 +47,7 @@ def _worker(rank, world, port, width, height, tile_rows, lanes, out_path):
         # every rank checks that it received a well-formed blob of the announced size
         magic, version, total = np.frombuffer(blob.numpy()[:16].tobytes(), dtype=np.uint32)[0], \
             np.frombuffer(blob.numpy()[:16].tobytes(), dtype=np.uint32)[1], np.frombuffer(blob.numpy()[8:16].tobytes(), dtype=np.uint64)[0]
-        assert magic == 0x52544231 and version == 6 and int(total) == blob.numel()
+        assert magic == 0x52544231 and version == 7 and int(total) == blob.numel()
 
         rows = shard.shard_row_indices(height, rank, world, tile_rows)
         assert len(rows) == rt.shard_rows(height, rank, world, tile_rows)

@@ -330,17 +330,18 @@ def test_compare_fixture_images():
 
 
 # ------------------------------------------------------------------ tree builder / blob
-HDR = struct.Struct("<IIQ5Q5II3IfI3f3f")
+HDR = struct.Struct("<IIQ5Q5II3IfI3f3fI")
 
 
 def _read_blob(blob):
     (magic, ver, total, o_nodes, o_tree, o_list, o_mat, o_light, n_pairs, n_tree, n_list, n_mat, n_light, root,
-     max_depth, max_leaf, n_leaves, sah, finite, gx, gy, gz, sx, sy, sz) = HDR.unpack_from(blob.tobytes()[:HDR.size])
-    assert magic == 0x52544231 and ver == 6 and total == len(blob)
+     max_depth, max_leaf, n_leaves, sah, finite, gx, gy, gz, sx, sy, sz, tree_kinds) = HDR.unpack_from(blob.tobytes()[:HDR.size])
+    assert magic == 0x52544231 and ver == 7 and total == len(blob)
     nodes = blob[o_nodes:o_nodes + 32 * n_pairs].view(np.uint32).reshape(n_pairs, 8)
     tree = blob[o_tree:o_tree + 48 * n_tree].view(np.uint32).reshape(n_tree, 12)
     lst = blob[o_list:o_list + 48 * n_list].view(np.uint32).reshape(n_list, 12)
-    return dict(nodes=nodes, tree=tree, list=lst, root=root, max_depth=max_depth, max_leaf=max_leaf, n_leaves=n_leaves,
+    assert tree_kinds == int(np.bitwise_or.reduce(np.uint32(1) << (tree[:, 3] & 3))) if n_tree else tree_kinds == 0      # one bit per kind of shape in the tree
+    return dict(nodes=nodes, tree=tree, list=lst, root=root, max_depth=max_depth, max_leaf=max_leaf, n_leaves=n_leaves, tree_kinds=tree_kinds,
                 n_mat=n_mat, n_light=n_light, origin=np.float64([gx, gy, gz]), scale=np.float64([sx, sy, sz]))
 
 
@@ -561,6 +562,7 @@ def test_builder_output_passes_the_blob_check():
     ("truncated", "size does not match its header"),
     ("magic", "bad magic or version"),
     ("orphan", "unreachable node pairs"),
+    ("sphere_among_triangles", "kinds of the tree's shapes differ from the header"),
 ])
 def test_damaged_blobs_are_rejected_before_they_reach_a_gpu(damage, msg):
     _, blob = _dragon_blob()
@@ -585,6 +587,9 @@ def test_damaged_blobs_are_rejected_before_they_reach_a_gpu(damage, msg):
         blob[0] ^= 0xFF
     elif damage == "orphan":
         nodes[inner[0], 3] = 0xFFFFFFFF      # drops a whole subtree
+    elif damage == "sphere_among_triangles":
+        assert b["tree_kinds"] == 2          # the header promises triangles only, which selects the kernel that tests nothing else
+        b["tree"][10, 3] &= ~np.uint32(3)    # kind 0: a sphere
     with pytest.raises(rt.RtError, match=msg):
         rt.validate_blob(blob)
 
