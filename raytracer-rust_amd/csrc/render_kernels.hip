@@ -292,33 +292,37 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
     // keeps descending towards its next one instead of idling (it then tests both).
     // A step is straight-line code: the two entries below the top are read while the node is on its way (a pop, and a
     // pop right after a pop, then cost no LDS round trip of their own), the rest are selects.
+    // The descent is a loop the whole wavefront goes round together, with the step under a condition of the lane's own
+    // (a lane whose `cur` is a leaf sits the rounds out): a loop that lanes leave one by one costs a dozen scalar
+    // instructions of mask bookkeeping per round more (2 % of the frame).
     uint32_t held = 0;                                  // leaf set aside (leaf references are never 0)
     for (;;) {
         MARK("closest_box");
-        while (!(cur & REF_LEAF)) {
-            const uint4* n = (const uint4*)((const char*)sc.nodes + cur);   // an inner reference is the pair's byte offset; 32 bits keep the address in one register
-            const uint4 c0 = n[0], c1 = n[1];
-            uint32_t below = low[64], below2 = low[0];
-            asm volatile("" : "+v"(below), "+v"(below2));       // keeps the reads here, under the node loads, instead of behind the box tests
-            float t0, t1;
-            bool h0 = slab(c0, rb, tlim, &t0);
-            bool h1 = slab(c1, rb, tlim, &t1);
-            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) cnt->wave_node_iters++; }
-            const uint32_t r0 = c0.w, r1 = c1.w;
-            const bool both = h0 && h1, any = h0 || h1, swap = t1 < t0;
-            const uint32_t far_child = swap ? r0 : r1;
-            low[128] = far_child;                               // a push when both are hit; otherwise a store to the free entry above the top, cheaper than a branch around it
-            // where the step leads, and what a pop would return from there
-            const uint32_t next = both ? (swap ? r1 : r0) : (any ? (h0 ? r0 : r1) : below);
-            const uint32_t under = both ? far_child : (any ? below : below2);
-            // a lane without a leaf in hand sets the one it has reached aside and goes on with what lies under it
-            const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
-            held = take ? next : held;
-            cur = take ? under : next;
-            low = (uint32_t*)((char*)low + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));   // 256 bytes: one entry of every lane
-            // nobody is still looking for a first leaf: no lane with empty hands and an inner node before it (one compare per lane)
-            if (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) == 0) break;
-        }
+        do {
+            if (!(cur & REF_LEAF)) {
+                const uint4* n = (const uint4*)((const char*)sc.nodes + cur);   // an inner reference is the pair's byte offset; 32 bits keep the address in one register
+                const uint4 c0 = n[0], c1 = n[1];
+                uint32_t below = low[64], below2 = low[0];
+                asm volatile("" : "+v"(below), "+v"(below2));       // keeps the reads here, under the node loads, instead of behind the box tests
+                float t0, t1;
+                bool h0 = slab(c0, rb, tlim, &t0);
+                bool h1 = slab(c1, rb, tlim, &t1);
+                if (COUNT) { cnt->nodes += 2; if (first_active_lane()) cnt->wave_node_iters++; }
+                const uint32_t r0 = c0.w, r1 = c1.w;
+                const bool both = h0 && h1, any = h0 || h1, swap = t1 < t0;
+                const uint32_t far_child = swap ? r0 : r1;
+                low[128] = far_child;                               // a push when both are hit; otherwise a store to the free entry above the top, cheaper than a branch around it
+                // where the step leads, and what a pop would return from there
+                const uint32_t next = both ? (swap ? r1 : r0) : (any ? (h0 ? r0 : r1) : below);
+                const uint32_t under = both ? far_child : (any ? below : below2);
+                // a lane without a leaf in hand sets the one it has reached aside and goes on with what lies under it
+                const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
+                held = take ? next : held;
+                cur = take ? under : next;
+                low = (uint32_t*)((char*)low + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));   // 256 bytes: one entry of every lane
+                // nobody is still looking for a first leaf: no lane with empty hands and an inner node before it (one compare per lane)
+            }
+        } while (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) != 0);
         MARK("closest_shape");
         if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf
             held = cur;
@@ -394,7 +398,6 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
     MARK("shadow_raybox");
     const RayBox rb = make_raybox(sc, o, d);
     float tlim = point_light ? prune_limit(light_dist) : INF;
-#ifndef RT_SHADOW_PLAIN_LOOP
     // The loop of closest_hit without the ordering: all lanes descend until each has a leaf in hand, and a lane that reaches its leaf
     // early sets it aside and goes on towards its next one instead of idling, then tests both.  (What it descends on behalf of a leaf
     // that turns out to hold an occluder is wasted; the lanes it no longer keeps waiting are worth more.)
@@ -402,26 +405,27 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
     uint32_t held = 0;
     for (;;) {
         MARK("shadow_box");
-        while (!(cur & REF_LEAF)) {
-            const uint4* n = (const uint4*)((const char*)sc.nodes + cur);   // an inner reference is the pair's byte offset; 32 bits keep the address in one register
-            const uint4 c0 = n[0], c1 = n[1];
-            uint32_t below = low[64], below2 = low[0];
-            asm volatile("" : "+v"(below), "+v"(below2));       // keeps the reads here, under the node loads, instead of behind the box tests
-            float t0, t1;
-            bool h0 = slab(c0, rb, tlim, &t0);
-            bool h1 = slab(c1, rb, tlim, &t1);
-            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) { cnt->wave_node_iters++; cnt->wave_shadow_node_iters++; } }
-            const uint32_t r0 = c0.w, r1 = c1.w;
-            const bool both = h0 && h1, any = h0 || h1;
-            low[128] = r1;                                      // as in closest_hit: a push, or a store to the free entry above the top
-            const uint32_t next = h0 ? r0 : (h1 ? r1 : below);
-            const uint32_t under = both ? r1 : (any ? below : below2);
-            const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
-            held = take ? next : held;
-            cur = take ? under : next;
-            low = (uint32_t*)((char*)low + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));   // 256 bytes: one entry of every lane
-            if (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) == 0) break;
-        }
+        do {
+            if (!(cur & REF_LEAF)) {
+                const uint4* n = (const uint4*)((const char*)sc.nodes + cur);   // an inner reference is the pair's byte offset; 32 bits keep the address in one register
+                const uint4 c0 = n[0], c1 = n[1];
+                uint32_t below = low[64], below2 = low[0];
+                asm volatile("" : "+v"(below), "+v"(below2));       // keeps the reads here, under the node loads, instead of behind the box tests
+                float t0, t1;
+                bool h0 = slab(c0, rb, tlim, &t0);
+                bool h1 = slab(c1, rb, tlim, &t1);
+                if (COUNT) { cnt->nodes += 2; if (first_active_lane()) { cnt->wave_node_iters++; cnt->wave_shadow_node_iters++; } }
+                const uint32_t r0 = c0.w, r1 = c1.w;
+                const bool both = h0 && h1, any = h0 || h1;
+                low[128] = r1;                                      // as in closest_hit: a push, or a store to the free entry above the top
+                const uint32_t next = h0 ? r0 : (h1 ? r1 : below);
+                const uint32_t under = both ? r1 : (any ? below : below2);
+                const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
+                held = take ? next : held;
+                cur = take ? under : next;
+                low = (uint32_t*)((char*)low + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));   // 256 bytes: one entry of every lane
+            }
+        } while (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) != 0);
         MARK("shadow_shape");
         if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf
             held = cur;
@@ -448,39 +452,6 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
         }
         if (cur == REF_EMPTY) break;
     }
-#else
-    uint32_t* low = stack;                              // as in closest_hit: the next free entry is low[128]
-    while (cur != REF_EMPTY) {
-        MARK("shadow_box");
-        while (!(cur & REF_LEAF)) {
-            const uint4* n = (const uint4*)((const char*)sc.nodes + cur);   // an inner reference is the pair's byte offset; 32 bits keep the address in one register
-            const uint4 c0 = n[0], c1 = n[1];
-            uint32_t below = low[64];
-            asm volatile("" : "+v"(below));       // keeps the read here, under the node loads, instead of behind the box tests
-            float t0, t1;
-            bool h0 = slab(c0, rb, tlim, &t0);
-            bool h1 = slab(c1, rb, tlim, &t1);
-            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) { cnt->wave_node_iters++; cnt->wave_shadow_node_iters++; } }
-            const uint32_t r0 = c0.w, r1 = c1.w;
-            const bool both = h0 && h1;
-            if (both) low[128] = r1;
-            cur = h0 ? r0 : (h1 ? r1 : below);
-            low += both ? 64 : ((h0 || h1) ? 0 : -64);
-        }
-        MARK("shadow_shape");
-        if (cur != REF_EMPTY) {
-            uint32_t first = (cur & ~REF_LEAF) >> 3, count = (cur & 7u) + 1u;
-            uint32_t below = low[64];
-            asm volatile("" : "+v"(below));       // read under the shape loads
-            for (uint32_t k = 0; k < count; k++) {
-                const float4* p = (const float4*)((const char*)sc.tree + (first + k) * 48u);      // fewer than 2^26 shapes: the byte offset fits 32 bits and the address one register
-                if (COUNT) { cnt->prims++; if (first_active_lane()) { cnt->wave_prim_iters++; cnt->wave_shadow_prim_iters++; } }
-                if (occludes<SITE_SHADOW_TREE>(p[0], p[1], p[2], o, d, hit_back, point_light, light_dist)) return true;
-            }
-            low -= 64; cur = below;
-        }
-    }
-#endif
     return false;
 }
 
@@ -516,29 +487,30 @@ __device__ __forceinline__ bool trace_job(const DevScene& sc, V3 o, V3 d, bool a
     uint32_t held = 0;
     for (;;) {
         MARK("round_box");
-        while (!(cur & REF_LEAF)) {
-            const uint4* n = (const uint4*)((const char*)sc.nodes + cur);
-            const uint4 c0 = n[0], c1 = n[1];
-            uint32_t below = low[64], below2 = low[0];
-            asm volatile("" : "+v"(below), "+v"(below2));
-            float t0, t1;
-            bool h0 = slab(c0, rb, tlim, &t0);
-            bool h1 = slab(c1, rb, tlim, &t1);
-            if (COUNT) { cnt->nodes += 2; if (first_active_lane()) { cnt->wave_node_iters++; cnt->wave_round_node_iters++; } }
-            const uint32_t r0 = c0.w, r1 = c1.w;
-            const bool both = h0 && h1, any = h0 || h1, swap = t1 < t0;
-            const uint32_t far_child = swap ? r0 : r1;
-            low[128] = far_child;
-            const uint32_t next = both ? (swap ? r1 : r0) : (any ? (h0 ? r0 : r1) : below);
-            const uint32_t under = both ? far_child : (any ? below : below2);
-            const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
-            held = take ? next : held;
-            cur = take ? under : next;
-            low = (uint32_t*)((char*)low + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));
-            if (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) == 0) break;
-        }
+        do {
+            if (!(cur & REF_LEAF)) {
+                const uint4* n = (const uint4*)((const char*)sc.nodes + cur);
+                const uint4 c0 = n[0], c1 = n[1];
+                uint32_t below = low[64], below2 = low[0];
+                asm volatile("" : "+v"(below), "+v"(below2));
+                float t0, t1;
+                bool h0 = slab(c0, rb, tlim, &t0);
+                bool h1 = slab(c1, rb, tlim, &t1);
+                if (COUNT) { cnt->nodes += 2; if (first_active_lane()) { cnt->wave_node_iters++; cnt->wave_round_node_iters++; } }
+                const uint32_t r0 = c0.w, r1 = c1.w;
+                const bool both = h0 && h1, any = h0 || h1, swap = t1 < t0;
+                const uint32_t far_child = swap ? r0 : r1;
+                low[128] = far_child;
+                const uint32_t next = both ? (swap ? r1 : r0) : (any ? (h0 ? r0 : r1) : below);
+                const uint32_t under = both ? far_child : (any ? below : below2);
+                const bool take = held == 0 && (next & REF_LEAF) && next != REF_EMPTY;
+                held = take ? next : held;
+                cur = take ? under : next;
+                low = (uint32_t*)((char*)low + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));
+            }
+        } while (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) != 0);
         MARK("round_shape");
-        if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {
+        if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf
             held = cur;
             low -= 64; cur = low[128];
         }
