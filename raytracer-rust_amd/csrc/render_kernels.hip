@@ -457,8 +457,10 @@ __device__ __forceinline__ bool in_shadow(const DevScene& sc, V3 o, V3 d, bool h
 
 
 // Most rounds of 64 jobs a side-by-side round may take (0: never, every ray is traced by its own lane, kind after kind).
+// One: the jobs of a level have to fit the wavefront (4K dragon: 2.51 ms; never 2.66; two rounds in place of three kinds,
+// which paid while the loops of the kinds were slower, 2.55).
 #ifndef RT_SIDE_ROUNDS_MAX
-#define RT_SIDE_ROUNDS_MAX 2u
+#define RT_SIDE_ROUNDS_MAX 1u
 #endif
 // One ray of either kind through the loop of closest_hit: a closest-hit ray as there, a shadow ray (any_hit) with the guards of
 // raytracer.rs:143-159 and an end at the first occluder.  For rounds in which the lanes of a wavefront carry rays of both kinds.
