@@ -629,7 +629,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
         V3 d = vnormalize(vadd(vadd(vscale(right, a), vscale(up, b)), cv));
         V3 o = v3(f.pos);
         const V3 ambient = v3(f.ambient);
-        const uint32_t jobs_per_hit = sc.n_lights + 1u;
 
         V3 cur = v3(0.0f, 0.0f, 0.0f);   // colour returned by the deepest level
         bool alive = live;
@@ -675,7 +674,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
             // ---- the rays that depend on this hit only, side by side when they fit
             const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
             const uint32_t n_alive = (uint32_t)__popcll(alive_mask);
-            // worth it when the jobs take fewer rounds of 64 than the one-after-the-other way takes passes (one per light and one for the next level)
+            // Worth it when the jobs take fewer rounds of 64 than the one-after-the-other way takes passes.  The jobs of a hit: a shadow
+            // ray per light, and the closest-hit ray of the next level unless no path of the wavefront goes on (the last level).
+            const uint32_t jobs_per_hit = sc.n_lights + (__builtin_amdgcn_ballot_w64(goes_on) != 0 ? 1u : 0u);
             const uint32_t n_jobs = n_alive * jobs_per_hit, n_rounds = (n_jobs + 63u) >> 6;
             const bool side_by_side = n_alive != 0u && n_rounds <= RT_SIDE_ROUNDS_MAX && n_rounds < jobs_per_hit && sc.n_lights <= 31u;      // the same in every lane
             uint32_t lit = 0;            // side by side: bit li set = light li is not occluded
@@ -729,9 +730,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
                         const uint32_t answer = pull(word, (first_job + li) & 63u);
                         if (((first_job + li) >> 6) == round) lit |= answer << li;
                     }
-                    const uint32_t next_prim = pull(word, (first_job + sc.n_lights) & 63u);
-                    const float next_t = pull(found.t, (first_job + sc.n_lights) & 63u);
-                    if (((first_job + sc.n_lights) >> 6) == round) { next.prim = next_prim; next.t = next_t; }
+                    if (jobs_per_hit > sc.n_lights) {                                           // (the same in every lane)
+                        const uint32_t next_prim = pull(word, (first_job + sc.n_lights) & 63u);
+                        const float next_t = pull(found.t, (first_job + sc.n_lights) & 63u);
+                        if (((first_job + sc.n_lights) >> 6) == round) { next.prim = next_prim; next.t = next_t; }
+                    }
                 }
                 have_next = true;
             }
