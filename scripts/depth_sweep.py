@@ -11,10 +11,10 @@ tracer = rt.RayTracer(cfg, device=0)
 f = cfg.frame()
 for md in (1, 2, 3, 4, 5):
     f.maxdepth = md
-    _, st = rt.render(f, count_work=True)
+    _, st = rt.render_frame(f, count_work=True)      # (frames left on the device: rt.render's stores into host memory would bound the short ones)
     ts = []
-    for _ in range(5):
-        _, s = rt.render(f)
+    for _ in range(8):
+        _, s = rt.render_frame(f, want_stats=True)
         ts.append(s["kernel_ms"])
     rays = st["primary"] + st["shadow"] + st["secondary"]
     print(f"maxdepth {md}: kernel {min(ts):.3f} ms  rays {rays/1e6:.2f}M (p {st['primary']/1e6:.2f} s {st['shadow']/1e6:.2f} r {st['secondary']/1e6:.2f}) "
