@@ -500,8 +500,8 @@ def main():
                 "bandwidth, because the caches serve these bytes (traffic is what reaches HBM).  A box is 16 B in the node layout, so the "
                 "kernel requests requested_bytes_per_launch; frac_of_requested_bytes is the same fraction with those.  The fields named in "
                 "counters_source come from committed rocprofv3 --pmc passes, not from this run.  What limits the kernel is vector ALU issue "
-                "(valu_issue_frac of the SIMDs' issue slots, 5 wavefronts per SIMD) spent at valu_lane_use of the lanes: a wavefront runs as "
-                "long as its slowest ray")
+                "(valu_issue_frac of the SIMDs' issue slots, 5 wavefronts per SIMD; instructions and cycles come from two counter passes, so a "
+                "full unit reads as 1.0 give or take a percent) spent at valu_lane_use of the lanes: a wavefront runs as long as its slowest ray")
         roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                     "traffic": pmc.get("hbm_bytes_per_launch"),
                     "kernel": "render_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes / launches,

@@ -84,6 +84,7 @@ struct State {
     // engine while the pieces that have arrived are copied on by the host's threads
     uint32_t* h_stage = nullptr; size_t stage_cap = 0;
     hipEvent_t piece_done[8] = {};
+    bool generic_kernel = false;                            // RT_RENDER_KERNEL=generic: every scene through the kernel that dispatches on the kind of shape (for comparisons)
     bool first_order_raster = false;                        // RT_FIRST_ORDER=raster: the first launch of a frame geometry hands its regions out in index order (for comparisons)
     bool stage_by_copy = false;                             // RT_RENDER_STAGING=copy: rt_render on one GPU copies the finished frame instead of rendering into host memory
     uint64_t scene_generation = 0;                          // bumped whenever another scene becomes resident
@@ -145,7 +146,7 @@ void point_at_blob(Device& dev, const rtl::BlobHeader& h) {
     dev.dsc.list = (const float4*)(base + h.off_list_shapes);
     dev.dsc.mats = (const float4*)(base + h.off_materials);
     dev.dsc.lights = (const float4*)(base + h.off_lights);
-    dev.dsc.n_list = h.n_list_shapes; dev.dsc.n_lights = h.n_lights; dev.dsc.root_ref = h.root_ref; dev.dsc.finite_shading = h.finite_shading; dev.dsc.tree_kinds = h.tree_kinds;
+    dev.dsc.n_list = h.n_list_shapes; dev.dsc.n_lights = h.n_lights; dev.dsc.root_ref = h.root_ref; dev.dsc.finite_shading = h.finite_shading; dev.dsc.tree_kinds = g.generic_kernel ? 0u : h.tree_kinds;
     for (int k = 0; k < 3; k++) {
         dev.dsc.grid_origin[k] = h.grid_origin[k]; dev.dsc.grid_scale[k] = h.grid_scale[k];
         dev.dsc.inv_limit[k] = std::fmin(1e30f, 1e32f / std::fmax(h.grid_scale[k], 1e-30f));     // 131072 * scale / d stays finite
@@ -437,6 +438,8 @@ int init_devices(int first_device, int count) {
     g.inited = true;
     const char* staging = std::getenv("RT_RENDER_STAGING");
     g.stage_by_copy = staging && std::strcmp(staging, "copy") == 0;
+    const char* kernel = std::getenv("RT_RENDER_KERNEL");
+    g.generic_kernel = kernel && std::strcmp(kernel, "generic") == 0;
     const char* first_order = std::getenv("RT_FIRST_ORDER");
     g.first_order_raster = first_order && std::strcmp(first_order, "raster") == 0;
     return 0;

@@ -259,6 +259,33 @@ def test_two_tracers_each_render_their_own_scene():
         rt.init(0)
 
 
+def test_kernel_for_trees_of_triangles_equals_the_generic_one():
+    """A tree that holds nothing but triangles is rendered by a build of the kernel without the dispatch on the kind of shape
+    and with the triangle test as straight-line code (all four rejections of shape.rs:152-176 combined at the end).  Same
+    frame as the generic build, pixel for pixel, on the dragon at its native size and from a camera inside the tree."""
+    cfg = rt.ParsedConfigState().load_config_file(os.path.join(GOLDEN, "final_avec_bonus.scene"))
+    scene = cfg.scene()
+    cam = cfg.camera
+    frames = [cfg.frame(), rt.frame_from_camera((0.3, 5.0, 0.2), cam["look_at"], cam["up"], 70.0, 800, 600, 6, cfg.ambient)]
+    got = {}
+    try:
+        for which in ("", "generic"):
+            rt.shutdown()
+            os.environ["RT_RENDER_KERNEL"] = which
+            rt.init(0)
+            rt.upload_scene(scene)
+            got[which] = [rt.render(f, count_work=True) for f in frames]
+    finally:
+        os.environ.pop("RT_RENDER_KERNEL", None)
+        rt.shutdown()
+        rt.init(0)
+    for (a, sa), (b, sb) in zip(got[""], got["generic"]):
+        assert np.array_equal(a, b)
+        assert sa["nodes_visited"] == sb["nodes_visited"] and sa["prims_tested"] == sb["prims_tested"] and sa["shadow"] == sb["shadow"]
+    golden = rt.file_to_image(os.path.join(GOLDEN, "dragon3.png"))
+    assert rt.Image.compare(rt.Image(640, 480, got[""][0][0]), golden)[0] == 0
+
+
 def test_first_frame_is_ordered_by_where_the_shapes_are_on_screen():
     """The first launch after an upload has no measured costs; its regions go by a guess: twice the tree shapes seen in a
     region plus their mirror images in the specular planes, summed over the five by five regions around it.  Checked
