@@ -19,6 +19,10 @@
 // Box culling is the only place with freedom: it is conservative (padded boxes, slack on the
 // pruning distance), so it never removes a shape the exact test would accept.
 //
+// The kernel is built twice: a tree that holds nothing but triangles (the blob header says what it holds) is rendered
+// by a build without the dispatch on the kind of shape and with the triangle test as straight-line code; its frames
+// are those of the generic build (RT_RENDER_KERNEL=generic in the environment selects that one for every scene).
+//
 // Reference code each part follows (paths relative to the reference tree):
 //   pixel loop / ray generation   src/raytracer/raytracer.rs:57-72
 //   quantise                      src/raytracer/raytracer.rs:85-91
@@ -320,8 +324,8 @@ __device__ __forceinline__ void closest_hit(const DevScene& sc, V3 o, V3 d, uint
                 held = take ? next : held;
                 cur = take ? under : next;
                 low = (uint32_t*)((char*)low + ((both ? 256 : (any ? 0 : -256)) + (take ? -256 : 0)));   // 256 bytes: one entry of every lane
-                // nobody is still looking for a first leaf: no lane with empty hands and an inner node before it (one compare per lane)
             }
+            // until nobody is still looking for a first leaf: no lane with empty hands and an inner node before it (one compare per lane)
         } while (__builtin_amdgcn_ballot_w64((held | (cur & REF_LEAF)) == 0u) != 0);
         MARK("closest_shape");
         if (held == 0 && (cur & REF_LEAF) && cur != REF_EMPTY) {  // the root or a popped entry can be a leaf

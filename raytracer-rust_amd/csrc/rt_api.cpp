@@ -208,8 +208,8 @@ int ensure_fold(Lane& lane, size_t npix, size_t levels) {
 // one-workgroup sort behind the kernel turns that into the order in which the next launch of the same frame
 // geometry hands its regions out: slowest first, cheap ones last to fill the end.  The first launch of a
 // geometry goes by a guess: regions by how many of the tree's shapes, and of their mirror images in the specular
-// planes, are seen in and around them (rtk_launch_predict_regions; 4K dragon: 3.05-3.1 ms against 3.4-3.6 in index order,
-// 2.9 with costs measured before, 2.8 in steady state).  Only the order of the work changes, never a pixel.
+// planes, are seen in and around them (rtk_launch_predict_regions; 4K dragon: a tenth over a frame ordered by measured
+// costs, against a quarter to a third in index order).  Only the order of the work changes, never a pixel.
 // Regions of a launch of local_rows rows of `width` pixels: side of a region in tiles as a power of two (0: the launch is
 // too small to be ordered) and how many regions there are across and down.
 struct RegionGrid { uint32_t log2, nx, ny; };
