@@ -544,7 +544,9 @@ struct CacheHeader {
 };
 static_assert(offsetof(CacheHeader, header_hash) == 1160 && sizeof(CacheHeader) == 1168, "cache header layout (no padding)");
 constexpr size_t CACHE_HEADER_BYTES = 4096;
-constexpr uint32_t CACHE_VERSION = 3;
+// The layout of this header (high half) and of the blob behind it (low half): a cache written before either changed is
+// "written by another version", which callers treat like a stale one (from_scene_file rebuilds it from the scene file).
+constexpr uint32_t CACHE_VERSION = (3u << 16) | rtl::BLOB_VERSION;
 const char CACHE_MAGIC[8] = {'R', 'T', 'S', 'C', 'A', 'C', 'H', 'E'};
 static_assert(sizeof(CacheHeader) <= CACHE_HEADER_BYTES, "cache header must fit its block");
 
