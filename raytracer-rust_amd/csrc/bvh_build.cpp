@@ -24,10 +24,12 @@ namespace {
 
 constexpr int NBINS = 32;
 // Cost model of the surface area heuristic.  Measured on the 4K dragon frame, ratios from 1:3 to
-// 2:1 and leaf caps of 2, 4 and 8 all land within 8 % of each other; 1:1 with a cap of 8 is best.
+// 2:1 and leaf caps of 2, 4 and 8 all land within 12 % of each other; 1:1 with a cap of 8 is best (2.47 ms; a shape at
+// 0.5 or 1.5 node pairs: 2.52 and 2.66; a cap of 2: 2.62).  RT_BVH_COST_SHAPE and RT_BVH_LEAF_CAP in the environment
+// override the two for such measurements (scripts/tree_sweep.sh).
 constexpr float COST_TRAVERSE = 1.0f;   // one node pair fetch + two slab tests
-constexpr float COST_SHAPE = 1.0f;      // one exact shape test
-constexpr uint32_t LEAF_CAP = rtl::MAX_LEAF;
+static const float COST_SHAPE = getenv("RT_BVH_COST_SHAPE") ? (float)atof(getenv("RT_BVH_COST_SHAPE")) : 1.0f;      // one exact shape test
+static const uint32_t LEAF_CAP = getenv("RT_BVH_LEAF_CAP") ? std::min(std::max((uint32_t)atoi(getenv("RT_BVH_LEAF_CAP")), 1u), rtl::MAX_LEAF) : rtl::MAX_LEAF;
 constexpr uint32_t PARALLEL_MIN = 8192; // subtrees above this size become OpenMP tasks
 constexpr uint32_t BIG_NODE = 1u << 18; // nodes above this size are themselves binned and partitioned in parallel
 constexpr uint32_t BIG_CHUNK = 1u << 15;
