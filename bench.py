@@ -450,7 +450,7 @@ def main():
     # Kernel-only duration (events bracketing just the kernel; the loop above brackets kernel + gather + reassembly),
     # the first frame of a freshly uploaded scene (no tile order from a previous launch yet), and the frame delivered to
     # host memory (the raytracer.rs:40 contract).
-    kernel_ms, cold_ms, host_ms, seeded_ms, cold_host_ms = [], None, None, None, None
+    kernel_ms, cold_ms, host_ms, seeded_ms, cold_host_ms, idle_ms = [], None, None, None, None, None
     if mode == "ranks":
         for _ in range(min(args.steps, 10)):
             kernel_ms.append(rt.render_tiles(frame, rank, world, target.data_ptr(), want_stats=True)["kernel_ms"])
@@ -464,8 +464,15 @@ def main():
             host_times.append(st_host["total_ms"])
         host_ms = float(np.mean(host_times[2:]))
         assert np.array_equal(host_frame, frame_host), "rt_render and rt_render_frame disagree"
+        # a warm frame (same scene, same measured order) that finds the GPU idle: what an idle GPU costs by itself, which every
+        # first frame below pays too (its upload leaves the GPU idle for longer than this)
+        idle_times = []
+        for _ in range(3):
+            time.sleep(0.1)
+            idle_times.append(rt.render_frame(frame, want_stats=True)[1]["kernel_ms"])
+        idle_ms = float(np.mean(idle_times))
         rt.upload_scene(scene, gpu_build=gpu_build)                       # a new resident scene: the tile order starts from scratch
-        cold_ms = rt.render_frame(frame, want_stats=True)[1]["kernel_ms"]
+        cold_ms = rt.render_frame(frame, want_stats=True)[1]["kernel_ms"]     # (includes the kernels that guess the order)
         # the reference's own timed region (main.rs:13-15): ONE render() of a scene that has just been built, frame delivered to the host
         rt.upload_scene(scene, gpu_build=gpu_build)
         cold_host_ms = rt.render(frame, out=host_frame)[1]["total_ms"]
@@ -544,6 +551,7 @@ def main():
             "scene_upload_s": upload_s,
             "step_ms_hip_events_mean": float(np.mean(step_ms_events)),
             "cold_first_frame_ms": cold_ms,
+            "warm_frame_on_idle_gpu_ms": idle_ms,
             "first_frame_with_saved_tile_costs_ms": seeded_ms,
             "rt_render_ms": host_ms,
             "cold_rt_render_ms": cold_host_ms,

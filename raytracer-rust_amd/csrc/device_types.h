@@ -39,7 +39,7 @@ struct DevFrame {
 
 
 constexpr uint32_t MAX_SORTED_REGIONS = 4096;
-#define RT_N_COUNTERS 15                         // 64-bit work counters of an instrumented launch (render_kernels.hip, rt_api.cpp)   // what one workgroup sorts in LDS
+#define RT_N_COUNTERS 15                         // 64-bit work counters of an instrumented launch (render_kernels.hip, rt_api.cpp)
 
 // Region size for a launch of tiles_x x tiles_y pixel tiles: 0 = row-major tile order.
 // Frames of fewer than 2048 tiles keep row-major order; otherwise the smallest regions (from 8x8 tiles up) that
@@ -78,12 +78,13 @@ inline RenderPlan rtk_render_plan(int stack_depth, uint32_t maxdepth) {
     return p;
 }
 
-// regions[order[i]] by decreasing cost into `order` (n <= MAX_SORTED_REGIONS), ties by index; the costs are moved to d_last
-// and d_cost is left zeroed.
-extern "C" hipError_t rtk_launch_sort_regions(uint32_t* d_cost, uint32_t n, uint32_t* d_order, uint32_t* d_last, hipStream_t stream);
+// regions[order[i]] by decreasing cost into `order` (n <= MAX_SORTED_REGIONS), ties by index; the costs are copied to d_last,
+// d_cost is left as it is and d_zeroed (n words, another array than d_cost) is cleared for the next launch to measure into.
+extern "C" hipError_t rtk_launch_sort_regions(const uint32_t* d_cost, uint32_t n, uint32_t* d_order, uint32_t* d_last, uint32_t* d_zeroed, hipStream_t stream);
 
 // Writes a guess at every region's cost to d_cost (n_regions words) from where the tree's shapes are on screen; for the
-// first launch of a frame geometry.  f: as for the launch, region fields filled in.  d_seen: n_regions words of scratch.
+// first launch of a frame geometry.  f: as for the launch, region fields filled in.  d_seen: n_regions words, all zero
+// (they come back holding counts).
 extern "C" hipError_t rtk_launch_predict_regions(const DevScene* sc, const DevFrame* f, uint32_t n_tree_shapes, uint32_t* d_seen, uint32_t* d_cost, hipStream_t stream);
 
 extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, uint32_t* d_out, float4* d_fold,

@@ -825,31 +825,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_WAVES, RT
     }
 }
 
-// Regions by decreasing measured cost (bitonic sort of one workgroup in LDS; keys cost << 32 | ~index so that
-// equal costs keep index order).
-// `padded`: the power of two the n keys are padded to (with keys that sort last).
-// The costs move on to `last` (what rt_tile_costs_export hands out) and `cost` is left at zero for the next launch to
-// measure into: no separate clearing launch per frame.
-__global__ __launch_bounds__(1024) void sort_regions_kernel(uint32_t* __restrict__ cost, uint32_t n, uint32_t padded, uint32_t* __restrict__ order,
-                                                            uint32_t* __restrict__ last) {
-    __shared__ unsigned long long keys[MAX_SORTED_REGIONS];
-    for (uint32_t i = threadIdx.x; i < padded; i += blockDim.x) {
-        const uint32_t c = i < n ? cost[i] : 0u;
-        keys[i] = i < n ? (((unsigned long long)c << 32) | (0xFFFFFFFFu - i)) : 0ull;
-        if (i < n) { last[i] = c; cost[i] = 0u; }
+// Regions by decreasing measured cost, ties by index: wavefront i counts the regions that come before region i (higher
+// cost, or the same cost and a lower index) and files i at that place.  n wavefronts with n / 64 loads each from an array
+// the L2 holds: a few microseconds, where one workgroup sorting in LDS took 22 (which every frame waits for).
+// The costs move on to `last` (what rt_tile_costs_export hands out).  Nothing may write `cost` while the wavefronts
+// read it, so the array that the next launch measures into is another one, `zeroed`, which this kernel clears:
+// no separate clearing launch per frame.
+__global__ __launch_bounds__(64) void rank_regions_kernel(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ order,
+                                                          uint32_t* __restrict__ last, uint32_t* __restrict__ zeroed) {
+    const uint32_t i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    const uint32_t mine = cost[i];
+    uint32_t before = 0;
+    for (uint32_t j = lane; j < n; j += 64u) {
+        const uint32_t c = cost[j];
+        before += (c > mine) | ((c == mine) & (j < i));
     }
-    __syncthreads();
-    for (uint32_t k = 2; k <= padded; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t p = threadIdx.x; p < (padded >> 1); p += blockDim.x) {       // one compare-exchange per thread
-                const uint32_t i = ((p & ~(j - 1u)) << 1) | (p & (j - 1u)), partner = i | j;
-                const bool descending = (i & k) == 0;
-                const unsigned long long a = keys[i], b = keys[partner];
-                if (descending ? a < b : a > b) { keys[i] = b; keys[partner] = a; }
-            }
-            __syncthreads();
-        }
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[i] = 0xFFFFFFFFu - (uint32_t)keys[i];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
+    if (lane == 0) { order[before] = i; last[i] = mine; zeroed[i] = 0u; }
 }
 
 // A guess at the costs of the tile regions for the first launch of a frame geometry, which has no measured ones yet:
@@ -857,7 +850,7 @@ __global__ __launch_bounds__(1024) void sort_regions_kernel(uint32_t* __restrict
 // wavefronts of a frame are those whose paths keep bouncing between shapes and their mirror images; raster order starts
 // the last of them late and ends the launch with a nearly empty GPU).  Every `step`-th tree shape is projected through
 // the frame's camera, as it is (counting twice: its paths start on it) and mirrored in each such plane (once), into the
-// region it lands in; counts are collected per workgroup in LDS and added to seen[].  A region's cost is then the sum
+// region it lands in; counts are collected per workgroup in LDS and added to seen[] (all zero before).  A region's cost is then the sum
 // over the five by five regions around it: what the slowest wavefront of a region costs varies a lot between
 // neighbours, and a smooth guess orders them better than a sharp one (measured on the 4K dragon frame from two
 // cameras).  Only the order of the work depends on this; the launch then measures the real costs for the ones after it.
@@ -951,19 +944,15 @@ extern "C" hipError_t rtk_launch_render(const DevScene* sc, const DevFrame* f, u
     return hipGetLastError();
 }
 
-extern "C" hipError_t rtk_launch_sort_regions(uint32_t* d_cost, uint32_t n, uint32_t* d_order, uint32_t* d_last, hipStream_t stream) {
-    if (n == 0 || n > MAX_SORTED_REGIONS) return hipErrorInvalidValue;
-    uint32_t padded = 2;
-    while (padded < n) padded <<= 1;
-    hipLaunchKernelGGL(sort_regions_kernel, dim3(1), dim3(padded < 1024 ? (padded < 64 ? 64 : padded) : 1024), 0, stream, d_cost, n, padded, d_order, d_last);
+extern "C" hipError_t rtk_launch_sort_regions(const uint32_t* d_cost, uint32_t n, uint32_t* d_order, uint32_t* d_last, uint32_t* d_zeroed, hipStream_t stream) {
+    if (n == 0 || n > MAX_SORTED_REGIONS || d_cost == d_zeroed) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rank_regions_kernel, dim3(n), dim3(64), 0, stream, d_cost, n, d_order, d_last, d_zeroed);
     return hipGetLastError();
 }
 
 extern "C" hipError_t rtk_launch_predict_regions(const DevScene* sc, const DevFrame* f, uint32_t n_tree_shapes, uint32_t* d_seen, uint32_t* d_cost, hipStream_t stream) {
     if (f->n_regions == 0) return hipSuccess;
     if (f->n_regions > MAX_SORTED_REGIONS || f->regions_x == 0 || f->n_regions % f->regions_x != 0 || f->nshards == 0 || f->tile_rows == 0) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(d_seen, 0, (size_t)f->n_regions * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
     if (n_tree_shapes != 0) {                                 // (no tree: nothing to go by, the costs come out equal)
         const uint32_t max_samples = 1u << 18, step = (n_tree_shapes + max_samples - 1u) / max_samples, samples = (n_tree_shapes + step - 1u) / step;
         const uint32_t blocks = std::min((samples + 255u) / 256u, 256u);

@@ -48,7 +48,11 @@ struct Lane {
     float4* d_fold = nullptr; size_t fold_cap = 0;          // records
     unsigned long long* d_counters = nullptr;               // nodes, prims, shadow, secondary, wave-level passes
     // order in which the tile regions of a launch are handed out, and what it was computed for
-    uint32_t* d_region_order = nullptr; uint32_t* d_region_cost = nullptr; uint32_t* d_region_last = nullptr; uint32_t region_cap = 0;   // cost: being measured; last: of the launch before
+    // cost: what the next launch measures into, all zero between launches; spare: the other array of that kind (the ordering
+    // kernel reads one and clears the other, then they change places); last: the costs of the launch before.  One allocation.
+    uint32_t* d_region_order = nullptr; uint32_t* d_region_cost = nullptr; uint32_t* d_region_spare = nullptr; uint32_t* d_region_last = nullptr;
+    uint32_t* d_region_block = nullptr; uint32_t region_cap = 0;
+    uint32_t region_n = 0;                                  // the first region_n words of cost are known to be zero, nothing else is written (0: cost and spare need clearing)
     RegionKey region_key{}; bool region_key_valid = false;
     // frames over several GPUs: this GPU's compact rows; on the first GPU the gathered rows of all and the frame
     uint32_t* d_rows = nullptr; size_t rows_cap = 0;
@@ -232,11 +236,30 @@ RegionKey region_key(const rt_frame& fr, uint32_t shard, uint32_t nshards, uint3
 int reserve_regions(Lane& lane, uint32_t n_regions) {
     if (n_regions <= lane.region_cap) return 0;
     if (lane.d_region_order) { (void)hipFree(lane.d_region_order); lane.d_region_order = nullptr; lane.region_cap = 0; }
-    if (lane.d_region_cost) { (void)hipFree(lane.d_region_cost); lane.d_region_cost = nullptr; lane.d_region_last = nullptr; }
+    if (lane.d_region_block) { (void)hipFree(lane.d_region_block); lane.d_region_block = lane.d_region_cost = lane.d_region_spare = lane.d_region_last = nullptr; }
     HIP_TRY(hipMalloc((void**)&lane.d_region_order, (size_t)n_regions * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&lane.d_region_cost, 2 * (size_t)n_regions * sizeof(uint32_t)));
-    lane.d_region_last = lane.d_region_cost + n_regions;
-    lane.region_cap = n_regions;
+    HIP_TRY(hipMalloc((void**)&lane.d_region_block, 3 * (size_t)n_regions * sizeof(uint32_t)));
+    lane.d_region_cost = lane.d_region_block; lane.d_region_spare = lane.d_region_block + n_regions; lane.d_region_last = lane.d_region_block + 2 * (size_t)n_regions;
+    lane.region_cap = n_regions; lane.region_n = 0;
+    return 0;
+}
+
+// Orders the regions by the costs in `from`, which is the lane's cost or spare array; afterwards the lane's cost array is
+// the one of the two that the kernel has cleared.
+int order_regions(Lane& lane, uint32_t* from, uint32_t n) {
+    uint32_t* other = from == lane.d_region_cost ? lane.d_region_spare : lane.d_region_cost;
+    HIP_TRY(rtk_launch_sort_regions(from, n, lane.d_region_order, lane.d_region_last, other, lane.stream));
+    lane.d_region_cost = other; lane.d_region_spare = from;
+    return 0;
+}
+
+// A launch of another geometry has another number of regions: what lies behind the words that the kernels of the last
+// one kept clear is stale.  (Same geometry, new scene: nothing to do.)
+int clear_regions_for(Lane& lane, uint32_t n) {
+    if (lane.region_n == n) return 0;
+    HIP_TRY(hipMemsetAsync(lane.d_region_block, 0, 2 * (size_t)lane.region_cap * sizeof(uint32_t), lane.stream));
+    lane.d_region_cost = lane.d_region_block; lane.d_region_spare = lane.d_region_block + lane.region_cap;
+    lane.region_n = n;
     return 0;
 }
 
@@ -249,12 +272,14 @@ int plan_regions(const Device& dev, Lane& lane, const rt_frame& fr, DevFrame* f)
     if (f->n_regions > MAX_SORTED_REGIONS) return 0;          // (frames beyond 200 megapixels: raster order of regions)
     const RegionKey key = region_key(fr, f->shard, f->nshards, f->tile_rows);
     if (!lane.region_key_valid || key != lane.region_key) {
-        if (reserve_regions(lane, f->n_regions)) return 1;
-        // No measured costs yet: the order follows a guess from where the tree's shapes are on screen (equal costs, i.e.
-        // index order, when there is nothing to go by or RT_FIRST_ORDER=raster asks for it).
-        if (g.first_order_raster) HIP_TRY(hipMemsetAsync(lane.d_region_cost, 0, (size_t)f->n_regions * sizeof(uint32_t), lane.stream));
-        else HIP_TRY(rtk_launch_predict_regions(&dev.dsc, f, g.hdr.n_tree_shapes, lane.d_region_last, lane.d_region_cost, lane.stream));   // (the sort then overwrites d_region_last)
-        HIP_TRY(rtk_launch_sort_regions(lane.d_region_cost, f->n_regions, lane.d_region_order, lane.d_region_last, lane.stream));
+        if (reserve_regions(lane, f->n_regions) || clear_regions_for(lane, f->n_regions)) return 1;
+        // No measured costs yet: the order follows a guess from where the tree's shapes are on screen, counted in the (clear)
+        // cost array and summed into the spare one; equal costs, i.e. index order, when RT_FIRST_ORDER=raster asks for it.
+        if (g.first_order_raster) { if (order_regions(lane, lane.d_region_cost, f->n_regions)) return 1; }
+        else {
+            HIP_TRY(rtk_launch_predict_regions(&dev.dsc, f, g.hdr.n_tree_shapes, lane.d_region_cost, lane.d_region_spare, lane.stream));
+            if (order_regions(lane, lane.d_region_spare, f->n_regions)) return 1;      // (clears the counts)
+        }
         lane.region_key = key; lane.region_key_valid = true;
     }
     f->region_order = lane.d_region_order;
@@ -310,10 +335,10 @@ int enqueue_shard(int d, const rt_frame* frame, uint32_t shard, uint32_t nshards
     const RenderPlan plan = rtk_render_plan((int)g.hdr.max_depth, frame->maxdepth);
     if (plan.lds_levels < levels && ensure_fold(lane, npix, levels - plan.lds_levels)) return 1;
     if (count_work) HIP_TRY(hipMemsetAsync(lane.d_counters, 0, RT_N_COUNTERS * sizeof(unsigned long long), lane.stream));
+    if (timed) HIP_TRY(hipEventRecord(lane.ev0, lane.stream));      // (before the planning: the kernels that order a first frame count as part of it)
     if (plan_regions(g.devs[d], lane, *frame, &f)) return 1;
-    if (timed) HIP_TRY(hipEventRecord(lane.ev0, lane.stream));
     HIP_TRY(rtk_launch_render(&g.devs[d].dsc, &f, d_out, lane.d_fold, lane.d_counters, (int)g.hdr.max_depth, plan, count_work, lane.stream));
-    if (f.region_cost) HIP_TRY(rtk_launch_sort_regions(f.region_cost, f.n_regions, lane.d_region_order, lane.d_region_last, lane.stream));
+    if (f.region_cost && order_regions(lane, f.region_cost, f.n_regions)) return 1;
     if (timed) HIP_TRY(hipEventRecord(lane.ev1, lane.stream));
     return 0;
 }
@@ -734,7 +759,8 @@ int rt_tile_costs_guess(const rt_frame* frame, int gpu, uint32_t* costs, uint32_
     f.region_log2 = grid.log2; f.regions_x = grid.nx; f.n_regions = n;
     uint32_t* d_guess = nullptr;                              // (the lane's own arrays belong to its launches)
     HIP_TRY(hipMalloc((void**)&d_guess, 2 * (size_t)n * sizeof(uint32_t)));
-    hipError_t e = rtk_launch_predict_regions(&g.devs[gpu].dsc, &f, g.hdr.n_tree_shapes, d_guess + n, d_guess, lane.stream);
+    hipError_t e = hipMemsetAsync(d_guess + n, 0, (size_t)n * sizeof(uint32_t), lane.stream);
+    if (e == hipSuccess) e = rtk_launch_predict_regions(&g.devs[gpu].dsc, &f, g.hdr.n_tree_shapes, d_guess + n, d_guess, lane.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(costs, d_guess, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, lane.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(lane.stream);
     (void)hipFree(d_guess);
@@ -751,9 +777,10 @@ int rt_tile_costs_import(const rt_frame* frame, int gpu, const uint32_t* costs, 
     if (use(gpu)) return 1;
     Lane& lane = cur(gpu);
     HIP_TRY(hipStreamSynchronize(lane.stream));
-    if (reserve_regions(lane, n)) return 1;
-    HIP_TRY(hipMemcpy(lane.d_region_cost, costs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(rtk_launch_sort_regions(lane.d_region_cost, n, lane.d_region_order, lane.d_region_last, lane.stream));
+    if (reserve_regions(lane, n) || clear_regions_for(lane, n)) return 1;
+    HIP_TRY(hipStreamSynchronize(lane.stream));
+    HIP_TRY(hipMemcpy(lane.d_region_spare, costs, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (order_regions(lane, lane.d_region_spare, n)) return 1;
     lane.region_key = key; lane.region_key_valid = true;
     return use(0);
 }
@@ -807,7 +834,7 @@ void rt_shutdown(void) {
             if (l.d_fold) (void)hipFree(l.d_fold);
             if (l.d_counters) (void)hipFree(l.d_counters);
             if (l.d_region_order) (void)hipFree(l.d_region_order);
-            if (l.d_region_cost) (void)hipFree(l.d_region_cost);
+            if (l.d_region_block) (void)hipFree(l.d_region_block);
             if (l.d_rows) (void)hipFree(l.d_rows);
             if (l.d_gathered) (void)hipFree(l.d_gathered);
             if (l.d_frame) (void)hipFree(l.d_frame);
