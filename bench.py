@@ -491,7 +491,12 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         rays_ps = primary + shadow
         rays_all = primary + shadow + secondary
-        k_ms = float(np.mean(kernel_ms))
+        k_sync_ms = float(np.mean(kernel_ms))
+        # The kernel's duration: on one GPU the HIP events of the timed region itself, recorded on the lane's stream around every
+        # step (render kernel plus the 5 us kernel behind it that orders the next launch's tiles, so a little more than the kernel);
+        # on several GPUs a step also holds the gather, and the library's events around the kernel of separately launched frames
+        # stand in (those launches find the GPU idle after the host's wait and run about 2 % longer).
+        k_ms = float(np.mean(step_ms_events)) if mode == "single" and lanes == 1 and step_ms_events else k_sync_ms
         my_primary, _, _, my_nodes, my_prims = (int(x) for x in mine.tolist())
         alg_bytes = 32 * my_nodes + 48 * my_prims + 4 * my_primary      # per launch (all GPUs together on the library path)
         requested = 16 * my_nodes + 48 * my_prims + 4 * my_primary      # what the kernel really asks the caches for: a box is 16 bytes in the node layout
@@ -503,7 +508,9 @@ def main():
         # 256 MB memory-side cache), so the memory-side bound of the traversal is the aggregate L2 bandwidth for both.
         bound, peak = "l2", L2_PEAK_GBS
         note = ("achieved and frac are measured in this run: algorithmic bytes (32 B x boxes tested + 48 B x shapes tested + 4 B x pixels, "
-                "counted by the instrumented kernel) over the kernel's duration by HIP events on its stream, against the aggregate L2 "
+                "counted by the instrumented kernel) over the kernel's duration by HIP events on its stream around every step of the timed "
+                "region (kernel_ms; kernel_ms_synchronous_launches: the library's own events around the kernel of frames launched one at a "
+                "time with a wait in between, which find the GPU idle), against the aggregate L2 "
                 "bandwidth, because the caches serve these bytes (traffic is what reaches HBM).  A box is 16 B in the node layout, so the "
                 "kernel requests requested_bytes_per_launch; frac_of_requested_bytes is the same fraction with those.  The fields named in "
                 "counters_source come from committed rocprofv3 --pmc passes, not from this run.  What limits the kernel is vector ALU issue "
@@ -511,7 +518,8 @@ def main():
                 "full unit reads as 1.0 give or take a percent) spent at valu_lane_use of the lanes: a wavefront runs as long as its slowest ray")
         roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                     "traffic": pmc.get("hbm_bytes_per_launch"),
-                    "kernel": "render_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes / launches,
+                    "kernel": "render_kernel", "kernel_ms": k_ms, "kernel_ms_synchronous_launches": k_sync_ms,
+                    "algorithmic_bytes_per_launch": alg_bytes / launches,
                     "requested_bytes_per_launch": requested / launches,
                     "frac_of_requested_bytes": requested / launches / (k_ms * 1e-3) / 1e9 / peak,
                     "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "note": note}
