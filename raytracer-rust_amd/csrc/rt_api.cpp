@@ -209,7 +209,7 @@ int ensure_fold(Lane& lane, size_t npix, size_t levels) {
 // raster order the last of them start late and the launch ends with most of a millisecond of nearly empty GPU.
 // So the frame is cut into square regions of tiles (which also keeps the rays in flight on one XCD close
 // together in the scene), every launch records the run time of the slowest wavefront of each region, and a
-// one-workgroup sort behind the kernel turns that into the order in which the next launch of the same frame
+// small ordering kernel behind it turns that into the order in which the next launch of the same frame
 // geometry hands its regions out: slowest first, cheap ones last to fill the end.  The first launch of a
 // geometry goes by a guess: regions by how many of the tree's shapes, and of their mirror images in the specular
 // planes, are seen in and around them (rtk_launch_predict_regions; 4K dragon: a tenth over a frame ordered by measured
