@@ -43,7 +43,7 @@ namespace rtg {
 namespace {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr float COST_BOX = 1.0f, COST_SHAPE = 1.0f;   // relative cost of one box-pair step and one shape test in the render kernel
+constexpr float COST_BOX = 1.0f, COST_SHAPE = 1.0f;   // relative cost of one box-pair step and one shape test in the render kernel (10 M-triangle mesh at 8K with the final kernel: 31.9 ms; 0.6: 34.5, 0.8: 32.2, 1.3: 32.1)
 
 // Monotone map float -> uint32 so that unsigned min/max atomics order floats.
 __device__ __forceinline__ uint32_t ordered(float f) { uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
