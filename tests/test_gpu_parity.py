@@ -81,6 +81,37 @@ def test_dragon_4k_against_oracle():
     print("dragon 3840x2160 vs oracle:", c, "kernel ms", tracer.last_stats["kernel_ms"])
 
 
+def test_dragon_from_random_cameras_against_oracle():
+    """The dragon's tree and rays from viewpoints the reference's scene file does not have: around, above, close to and inside the
+    dragon, from below the mirror plane, with odd frame sizes, fields of view from 5 to 120 degrees and maxdepth 1 to 7.  Each
+    frame against the oracle's render from the same camera (frame set-up raytracer.rs:41-55 on both sides)."""
+    path = os.path.join(GOLDEN, "final_avec_bonus.scene")
+    cfg = rt.ParsedConfigState().load_config_file(path)
+    rt.RayTracer.new(cfg)
+    osc = O.OracleScene.load(path)
+    rng = np.random.default_rng(20261112)
+    worst = 1.0
+    for k in range(10):
+        if k < 6:
+            pos = rng.uniform(-1, 1, 3) * (25.0, 20.0, 25.0) + (0.0, 12.0, 0.0)
+        elif k < 8:
+            pos = rng.uniform(-1, 1, 3) * (2.0, 3.0, 2.0) + (0.0, 5.0, -1.0)       # among the dragon's triangles
+        else:
+            pos = rng.uniform(-1, 1, 3) * (15.0, 15.0, 3.0) + (0.0, 5.0, -9.0)      # behind the plane z = -5
+        look = rng.uniform(-1, 1, 3) * (3.0, 3.0, 3.0) + (0.0, 5.0, -1.0)
+        up = (0.0, 1.0, 0.0) if k % 3 else tuple(rng.uniform(-1, 1, 3))
+        fov = float(rng.choice([5.0, 20.0, 45.0, 90.0, 120.0]))
+        w, h, depth = int(rng.integers(40, 400)), int(rng.integers(30, 300)), int(rng.integers(1, 8))
+        frame = rt.frame_from_camera(tuple(pos), tuple(look), up, fov, w, h, depth, cfg.ambient)
+        got, st = rt.render(frame, count_work=True)
+        osc.set_frame(w, h, depth, list(pos) + list(look) + list(up) + [fov], cfg.ambient)
+        want, ost = osc.render(mode=O.OracleScene.MODE_TREE_PRUNED)
+        c = _assert_parity(got, want)
+        assert (st["primary"], st["shadow"], st["secondary"]) == (ost["primary"], ost["shadow"], ost["secondary"]), (k, st, ost)
+        worst = min(worst, c["identical_frac"])
+    print("dragon from 10 random cameras vs oracle: least identical fraction", worst)
+
+
 def test_test_scene_full_size_against_oracle():
     path = os.path.join(GOLDEN, "test.scene")
     cfg = rt.ParsedConfigState().load_config_file(path)
