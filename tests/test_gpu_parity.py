@@ -180,6 +180,29 @@ def test_random_scenes_against_exhaustive_oracle(seed, ntri, nsph, npl, nlights,
         assert (img.data == 0xFF000000).all()
 
 
+@pytest.mark.parametrize("gpu_build", [False, True], ids=["host_tree", "gpu_tree"])
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_random_scenes_from_random_cameras_against_exhaustive_oracle(seed, gpu_build):
+    """Mixed trees (triangles, spheres; planes in the always-tested list), point and directional lights, seen from a random
+    viewpoint that is as likely inside the cloud of shapes as outside it, through both tree builders: every pixel within
+    tolerance of the oracle that tests every shape for every ray, and the same number of rays of each kind."""
+    rng = np.random.default_rng(seed)
+    ntri, nsph, npl = int(rng.integers(0, 400)), int(rng.integers(0, 80)), int(rng.integers(0, 3))
+    text = _random_scene(rng, ntri, nsph, npl, int(rng.integers(1, 4)), int(rng.integers(1, 8)), size=(int(rng.integers(30, 130)), int(rng.integers(20, 90))))
+    pos, look = rng.uniform(-7, 7, 3), rng.uniform(-2, 2, 3)
+    up = rng.uniform(-1, 1, 3)
+    camera = "camera " + " ".join(f"{v:.4f}" for v in (*pos, *look, *up)) + f" {rng.choice([10, 35, 60, 100])}"
+    text = text.replace("camera 0 1 9 0 0 0 0 1 0 50", camera)
+    assert camera in text
+    cfg = rt.ParsedConfigState().parse_text(text)
+    tracer = rt.RayTracer(cfg, gpu_build=gpu_build)
+    img = tracer.render(count_work=True)
+    want, st = O.OracleScene.parse(text).render(mode=O.OracleScene.MODE_ALL)
+    _assert_parity(img.pixels(), want)
+    got = tracer.last_stats
+    assert (got["primary"], got["shadow"], got["secondary"]) == (st["primary"], st["shadow"], st["secondary"])
+
+
 @pytest.mark.parametrize("size", [(1, 1), (7, 5), (8, 8), (9, 17), (333, 3)])
 def test_ragged_frame_sizes(size):
     path = os.path.join(GOLDEN, "test_file", "jalon6", "tp64.test")
